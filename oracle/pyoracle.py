@@ -1,0 +1,284 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-ends for the two checkers.
+
+* ``Oracle``     : oracle/libspeedy_oracle.so, the plain-C restatement (speedy_oracle.c).
+* ``Reference``  : oracle/_ref/libspeedy_ref_<tag>.so, the real reference hot path compiled
+                   by flang from /root/reference/source (build_ref.sh) behind ref_shim.f90.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (speedy.f90_amd) never does.
+
+Array conventions (NumPy C-order views of the reference's column-major arrays):
+    grid  g(ix,il)          -> float64   [il, ix]
+    spec  s(mx,nx) complex  -> complex128[nx, mx]
+    four  f(2*mx,il)        -> float64   [il, 2*mx]
+    3-D spectral (mx,nx,kx) -> complex128[kx, nx, mx]
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RESOLUTIONS = {"t30": (30, 96, 24, 8), "t63": (63, 192, 48, 8)}  # trunc, ix, iy, kx
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def build(quiet=True):
+    """Compile the C restatement (+ the flang reference when its sources are present)."""
+    out = subprocess.DEVNULL if quiet else None
+    subprocess.check_call(["make", "-C", _HERE, "all"], stdout=out)
+
+
+class _Dims:
+    def _set_dims(self, trunc, ix, iy, kx):
+        self.trunc, self.ix, self.iy, self.kx = trunc, ix, iy, kx
+        self.il, self.nx, self.mx = 2 * iy, trunc + 2, trunc + 1
+        self.grid_shape = (self.il, self.ix)
+        self.spec_shape = (self.nx, self.mx)
+        self.four_shape = (self.il, 2 * self.mx)
+
+
+class Oracle(_Dims):
+    """C restatement of the reference algorithm (scalar, one field at a time)."""
+
+    def __init__(self, trunc=30, ix=96, iy=24, kx=8):
+        path = os.path.join(_HERE, "libspeedy_oracle.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = ctypes.CDLL(path)
+        self.lib.orc_create.restype = ctypes.c_void_p
+        self.lib.orc_create.argtypes = [ctypes.c_int] * 4
+        self.lib.orc_get_table.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+        self._set_dims(trunc, ix, iy, kx)
+        self.ctx = ctypes.c_void_p(self.lib.orc_create(trunc, ix, iy, kx))
+        if not self.ctx:
+            raise RuntimeError("orc_create failed")
+
+    def __del__(self):
+        if getattr(self, "ctx", None):
+            self.lib.orc_destroy(self.ctx)
+            self.ctx = None
+
+    def table(self, name):
+        n = self.lib.orc_get_table(self.ctx, name.encode(), None) if name not in ("ifac", "nsh2") else 64
+        if n < 0:
+            raise KeyError(name)
+        out = np.zeros(n)
+        n = self.lib.orc_get_table(self.ctx, name.encode(), _ptr(out))
+        return out[:n]
+
+    # --- stage / API entry points (one 2-D field) ---
+    def fourier_inv(self, f, kcos=1):
+        f = _f64(f); g = np.empty(self.grid_shape)
+        self.lib.orc_fourier_inv(self.ctx, _ptr(f), ctypes.c_int(kcos), _ptr(g)); return g
+
+    def fourier_dir(self, g):
+        g = _f64(g); f = np.empty(self.four_shape)
+        self.lib.orc_fourier_dir(self.ctx, _ptr(g), _ptr(f)); return f
+
+    def legendre_inv(self, s):
+        s = _c128(s); f = np.empty(self.four_shape)
+        self.lib.orc_legendre_inv(self.ctx, _ptr(s), _ptr(f)); return f
+
+    def legendre_dir(self, f):
+        f = _f64(f); s = np.empty(self.spec_shape, np.complex128)
+        self.lib.orc_legendre_dir(self.ctx, _ptr(f), _ptr(s)); return s
+
+    def spec_to_grid(self, s, kcos=1):
+        s = _c128(s); g = np.empty(self.grid_shape)
+        self.lib.orc_spec_to_grid(self.ctx, _ptr(s), ctypes.c_int(kcos), _ptr(g)); return g
+
+    def grid_to_spec(self, g):
+        g = _f64(g); s = np.empty(self.spec_shape, np.complex128)
+        self.lib.orc_grid_to_spec(self.ctx, _ptr(g), _ptr(s)); return s
+
+    def laplacian(self, a):
+        a = _c128(a); o = np.empty_like(a); self.lib.orc_laplacian(self.ctx, _ptr(a), _ptr(o)); return o
+
+    def inverse_laplacian(self, a):
+        a = _c128(a); o = np.empty_like(a); self.lib.orc_inverse_laplacian(self.ctx, _ptr(a), _ptr(o)); return o
+
+    def trunct(self, a):
+        a = _c128(a).copy(); self.lib.orc_trunct(self.ctx, _ptr(a)); return a
+
+    def grad(self, psi):
+        psi = _c128(psi); dx = np.zeros_like(psi); dy = np.zeros_like(psi)
+        self.lib.orc_grad(self.ctx, _ptr(psi), _ptr(dx), _ptr(dy)); return dx, dy
+
+    def vds(self, ucosm, vcosm):
+        u = _c128(ucosm); v = _c128(vcosm); vor = np.zeros_like(u); div = np.zeros_like(u)
+        self.lib.orc_vds(self.ctx, _ptr(u), _ptr(v), _ptr(vor), _ptr(div)); return vor, div
+
+    def uvspec(self, vorm, divm):
+        a = _c128(vorm); b = _c128(divm); u = np.zeros_like(a); v = np.zeros_like(a)
+        self.lib.orc_uvspec(self.ctx, _ptr(a), _ptr(b), _ptr(u), _ptr(v)); return u, v
+
+    def vdspec(self, ug, vg, kcos=2):
+        ug = _f64(ug); vg = _f64(vg)
+        vor = np.zeros(self.spec_shape, np.complex128); div = np.zeros_like(vor)
+        self.lib.orc_vdspec(self.ctx, _ptr(ug), _ptr(vg), _ptr(vor), _ptr(div), ctypes.c_int(kcos))
+        return vor, div
+
+    # --- spectral-space tail ---
+    def tail_init(self, dt):
+        rc = self.lib.orc_tail_init(self.ctx, ctypes.c_double(dt))
+        if rc != 0:
+            raise RuntimeError("orc_tail_init rc=%d" % rc)
+
+    def hdiff(self, field, fdt_in, dmp, dmp1):
+        field = _c128(field); fdt_in = _c128(fdt_in); dmp = _f64(dmp); dmp1 = _f64(dmp1)
+        nlev = 1 if field.ndim == 2 else field.shape[0]
+        out = np.empty_like(field)
+        self.lib.orc_hdiff(self.ctx, ctypes.c_int(nlev), _ptr(field), _ptr(fdt_in), _ptr(dmp), _ptr(dmp1), _ptr(out))
+        return out
+
+    def implicit_terms(self, divdt, tdt, psdt):
+        d = _c128(divdt).copy(); t = _c128(tdt).copy(); p = _c128(psdt).copy()
+        self.lib.orc_implicit_terms(self.ctx, _ptr(d), _ptr(t), _ptr(p)); return d, t, p
+
+    def roundtrip_loop(self, g_in, nrep=1):
+        g_in = _f64(g_in); out = np.empty_like(g_in)
+        self.lib.orc_roundtrip_loop(self.ctx, ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))
+        return out
+
+
+class Reference(_Dims):
+    """The real reference hot path (flang build).  Raises FileNotFoundError if not built."""
+
+    @staticmethod
+    def available(tag="t30"):
+        return os.path.exists(os.path.join(_HERE, "_ref", "libspeedy_ref_%s.so" % tag))
+
+    def __init__(self, tag="t30"):
+        path = os.path.join(_HERE, "_ref", "libspeedy_ref_%s.so" % tag)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = ctypes.CDLL(path)
+        d = (ctypes.c_int * 7)()
+        self.lib.ref_dims(d)
+        self._set_dims(d[0], d[1], d[2], d[4])
+        assert (self.il, self.nx, self.mx) == (d[3], d[5], d[6])
+        self.lib.ref_init()
+        self.tag = tag
+
+    def geometry(self):
+        a = np.zeros(self.iy); b = np.zeros(self.il); c = np.zeros(self.il); d = np.zeros(self.il)
+        self.lib.ref_get_geometry(_ptr(a), _ptr(b), _ptr(c), _ptr(d))
+        return {"sia_half": a, "coa_half": b, "cosgr": c, "cosgr2": d}
+
+    def sigma(self):
+        k = self.kx
+        t = [np.zeros(k + 1), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)]
+        self.lib.ref_get_sigma(*[_ptr(x) for x in t])
+        return dict(zip(["hsg", "dhs", "fsg", "dhsr", "fsgr"], t))
+
+    def rffti1(self, n=None):
+        n = n or self.ix
+        wa = np.zeros(n); ifac = (ctypes.c_int * 15)()
+        self.lib.ref_rffti1(ctypes.c_int(n), _ptr(wa), ifac)
+        return wa, np.array(list(ifac), dtype=np.int32)
+
+    def rfftb1(self, c):
+        c = _f64(c).copy(); wa, ifac = self.rffti1(c.size)
+        self.lib.ref_rfftb1(ctypes.c_int(c.size), _ptr(c), _ptr(wa), _ptr(ifac)); return c
+
+    def rfftf1(self, c):
+        c = _f64(c).copy(); wa, ifac = self.rffti1(c.size)
+        self.lib.ref_rfftf1(ctypes.c_int(c.size), _ptr(c), _ptr(wa), _ptr(ifac)); return c
+
+    def epsi(self):
+        o = np.zeros((self.nx + 1, self.mx + 1)); self.lib.ref_get_epsi(_ptr(o)); return o
+
+    def el2(self):
+        o = np.zeros((self.nx, self.mx)); self.lib.ref_get_el2(_ptr(o)); return o
+
+    def fourier_inv(self, f, kcos=1):
+        f = _f64(f); g = np.empty(self.grid_shape)
+        self.lib.ref_fourier_inv(_ptr(f), ctypes.c_int(kcos), _ptr(g)); return g
+
+    def fourier_dir(self, g):
+        g = _f64(g); f = np.empty(self.four_shape)
+        self.lib.ref_fourier_dir(_ptr(g), _ptr(f)); return f
+
+    def legendre_inv(self, s):
+        s = _c128(s); f = np.empty(self.four_shape)
+        self.lib.ref_legendre_inv(_ptr(s), _ptr(f)); return f
+
+    def legendre_dir(self, f):
+        f = _f64(f); s = np.empty(self.spec_shape, np.complex128)
+        self.lib.ref_legendre_dir(_ptr(f), _ptr(s)); return s
+
+    def spec_to_grid(self, s, kcos=1):
+        s = _c128(s); g = np.empty(self.grid_shape)
+        self.lib.ref_spec_to_grid(_ptr(s), ctypes.c_int(kcos), _ptr(g)); return g
+
+    def grid_to_spec(self, g):
+        g = _f64(g); s = np.empty(self.spec_shape, np.complex128)
+        self.lib.ref_grid_to_spec(_ptr(g), _ptr(s)); return s
+
+    def laplacian(self, a):
+        a = _c128(a); o = np.empty_like(a); self.lib.ref_laplacian(_ptr(a), _ptr(o)); return o
+
+    def inverse_laplacian(self, a):
+        a = _c128(a); o = np.empty_like(a); self.lib.ref_inverse_laplacian(_ptr(a), _ptr(o)); return o
+
+    def trunct(self, a):
+        a = _c128(a).copy(); self.lib.ref_trunct(_ptr(a)); return a
+
+    def grad(self, psi):
+        psi = _c128(psi).copy(); dx = np.zeros_like(psi); dy = np.zeros_like(psi)
+        self.lib.ref_grad(_ptr(psi), _ptr(dx), _ptr(dy)); return dx, dy
+
+    def vds(self, ucosm, vcosm):
+        u = _c128(ucosm).copy(); v = _c128(vcosm).copy(); vor = np.zeros_like(u); div = np.zeros_like(u)
+        self.lib.ref_vds(_ptr(u), _ptr(v), _ptr(vor), _ptr(div)); return vor, div
+
+    def uvspec(self, vorm, divm):
+        a = _c128(vorm); b = _c128(divm); u = np.zeros_like(a); v = np.zeros_like(a)
+        self.lib.ref_uvspec(_ptr(a), _ptr(b), _ptr(u), _ptr(v)); return u, v
+
+    def vdspec(self, ug, vg, kcos=2):
+        ug = _f64(ug); vg = _f64(vg)
+        vor = np.zeros(self.spec_shape, np.complex128); div = np.zeros_like(vor)
+        self.lib.ref_vdspec(_ptr(ug), _ptr(vg), _ptr(vor), _ptr(div), ctypes.c_int(kcos))
+        return vor, div
+
+    def tail_init(self, dt):
+        self.lib.ref_tail_init(ctypes.c_double(dt))
+
+    def dmp_tables(self):
+        t = [np.zeros((self.nx, self.mx)) for _ in range(6)]
+        self.lib.ref_get_dmp(*[_ptr(x) for x in t])
+        return dict(zip(["dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s"], t))
+
+    def tref_tables(self):
+        t = [np.zeros(self.kx) for _ in range(3)]
+        self.lib.ref_get_tref(*[_ptr(x) for x in t])
+        return dict(zip(["tref", "tref2", "tref3"], t))
+
+    def hdiff(self, field, fdt_in, dmp, dmp1):
+        field = _c128(field); fdt_in = _c128(fdt_in); dmp = _f64(dmp); dmp1 = _f64(dmp1)
+        out = np.empty_like(field)
+        fn = self.lib.ref_hdiff_2d if field.ndim == 2 else self.lib.ref_hdiff_3d
+        fn(_ptr(field), _ptr(fdt_in), _ptr(dmp), _ptr(dmp1), _ptr(out)); return out
+
+    def implicit_terms(self, divdt, tdt, psdt):
+        d = _c128(divdt).copy(); t = _c128(tdt).copy(); p = _c128(psdt).copy()
+        self.lib.ref_implicit_terms(_ptr(d), _ptr(t), _ptr(p)); return d, t, p
+
+    def roundtrip_loop(self, g_in, nrep=1):
+        g_in = _f64(g_in); out = np.empty_like(g_in)
+        self.lib.ref_roundtrip_loop(ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))
+        return out

@@ -1,0 +1,305 @@
+! TEST INFRASTRUCTURE ONLY -- never linked into, imported by or called from the product path.
+!
+! bind(C) shim over the *public* API of the reference's hot-path modules
+! (/root/reference/source/{geometry,fourier,legendre,spectral,horizontal_diffusion,implicit}.f90).
+! oracle/build_ref.sh compiles the reference sources where they lie, together with this
+! file, into oracle/_ref/libspeedy_ref_<res>.so.  Nothing of the reference is copied here:
+! every routine below only forwards to a reference procedure and moves data across the C ABI.
+!
+! Array shapes come from the reference's compile-time `params` module, so the same shim
+! serves the stock T30 build and the T63 build (params.f90 patched in a scratch dir).
+
+subroutine ref_dims(d) bind(C, name="ref_dims")
+    use iso_c_binding
+    use params, only: trunc, ix, iy, il, kx, nx, mx
+    integer(c_int), intent(out) :: d(7)
+    d = (/ trunc, ix, iy, il, kx, nx, mx /)
+end subroutine
+
+! geometry.f90:35 initialize_geometry ; spectral.f90:20 initialize_spectral
+subroutine ref_init() bind(C, name="ref_init")
+    use geometry, only: initialize_geometry
+    use spectral, only: initialize_spectral
+    call initialize_geometry
+    call initialize_spectral
+end subroutine
+
+! geometry.f90:11-31 public latitude tables
+subroutine ref_get_geometry(o_sia_half, o_coa_half, o_cosgr, o_cosgr2) bind(C, name="ref_get_geometry")
+    use iso_c_binding
+    use params, only: iy, il
+    use geometry, only: sia_half, coa_half, cosgr, cosgr2
+    real(c_double), intent(out) :: o_sia_half(iy), o_coa_half(il), o_cosgr(il), o_cosgr2(il)
+    o_sia_half = sia_half
+    o_coa_half = coa_half
+    o_cosgr = cosgr
+    o_cosgr2 = cosgr2
+end subroutine
+
+! geometry.f90:14-18 sigma-level tables
+subroutine ref_get_sigma(o_hsg, o_dhs, o_fsg, o_dhsr, o_fsgr) bind(C, name="ref_get_sigma")
+    use iso_c_binding
+    use params, only: kx
+    use geometry, only: hsg, dhs, fsg, dhsr, fsgr
+    real(c_double), intent(out) :: o_hsg(kx+1), o_dhs(kx), o_fsg(kx), o_dhsr(kx), o_fsgr(kx)
+    o_hsg = hsg
+    o_dhs = dhs
+    o_fsg = fsg
+    o_dhsr = dhsr
+    o_fsgr = fsgr
+end subroutine
+
+! fftpack.f90:1 rffti1 (external subroutine)
+subroutine ref_rffti1(n, wa, ifac) bind(C, name="ref_rffti1")
+    use iso_c_binding
+    integer(c_int), value :: n
+    real(c_double), intent(inout) :: wa(n)
+    integer(c_int), intent(inout) :: ifac(15)
+    external rffti1
+    call rffti1(n, wa, ifac)
+end subroutine
+
+! fftpack.f90:69 rfftb1 / :136 rfftf1 on one length-n vector (c in place, ch scratch)
+subroutine ref_rfftb1(n, c, wa, ifac) bind(C, name="ref_rfftb1")
+    use iso_c_binding
+    integer(c_int), value :: n
+    real(c_double), intent(inout) :: c(n), wa(n)
+    integer(c_int), intent(in) :: ifac(15)
+    real(c_double) :: ch(n)
+    external rfftb1
+    call rfftb1(n, c, ch, wa, ifac)
+end subroutine
+
+subroutine ref_rfftf1(n, c, wa, ifac) bind(C, name="ref_rfftf1")
+    use iso_c_binding
+    integer(c_int), value :: n
+    real(c_double), intent(inout) :: c(n), wa(n)
+    integer(c_int), intent(in) :: ifac(15)
+    real(c_double) :: ch(n)
+    external rfftf1
+    call rfftf1(n, c, ch, wa, ifac)
+end subroutine
+
+! legendre.f90:12 public epsi ; spectral.f90:8 public el2
+subroutine ref_get_epsi(o) bind(C, name="ref_get_epsi")
+    use iso_c_binding
+    use params, only: mx, nx
+    use legendre, only: epsi
+    real(c_double), intent(out) :: o(mx+1,nx+1)
+    o = epsi
+end subroutine
+
+subroutine ref_get_el2(o) bind(C, name="ref_get_el2")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: el2
+    real(c_double), intent(out) :: o(mx,nx)
+    o = el2
+end subroutine
+
+! fourier.f90:23 fourier_inv ; fourier.f90:56 fourier_dir
+subroutine ref_fourier_inv(f, kcos, g) bind(C, name="ref_fourier_inv")
+    use iso_c_binding
+    use params, only: mx, ix, il
+    use fourier, only: fourier_inv
+    real(c_double), intent(in) :: f(2*mx,il)
+    integer(c_int), value :: kcos
+    real(c_double), intent(out) :: g(ix,il)
+    g = fourier_inv(f, kcos)
+end subroutine
+
+subroutine ref_fourier_dir(g, f) bind(C, name="ref_fourier_dir")
+    use iso_c_binding
+    use params, only: mx, ix, il
+    use fourier, only: fourier_dir
+    real(c_double), intent(in) :: g(ix,il)
+    real(c_double), intent(out) :: f(2*mx,il)
+    f = fourier_dir(g)
+end subroutine
+
+! legendre.f90:74 legendre_inv ; legendre.f90:114 legendre_dir
+subroutine ref_legendre_inv(s, f) bind(C, name="ref_legendre_inv")
+    use iso_c_binding
+    use params, only: mx, nx, il
+    use legendre, only: legendre_inv
+    real(c_double), intent(in) :: s(2*mx,nx)
+    real(c_double), intent(out) :: f(2*mx,il)
+    f = legendre_inv(s)
+end subroutine
+
+subroutine ref_legendre_dir(f, s) bind(C, name="ref_legendre_dir")
+    use iso_c_binding
+    use params, only: mx, nx, il
+    use legendre, only: legendre_dir
+    real(c_double), intent(in) :: f(2*mx,il)
+    real(c_double), intent(out) :: s(2*mx,nx)
+    s = legendre_dir(f)
+end subroutine
+
+! spectral.f90:98 spec_to_grid ; spectral.f90:112 grid_to_spec
+subroutine ref_spec_to_grid(s, kcos, g) bind(C, name="ref_spec_to_grid")
+    use iso_c_binding
+    use params, only: mx, nx, ix, il
+    use spectral, only: spec_to_grid
+    complex(c_double_complex), intent(in) :: s(mx,nx)
+    integer(c_int), value :: kcos
+    real(c_double), intent(out) :: g(ix,il)
+    g = spec_to_grid(s, kcos)
+end subroutine
+
+subroutine ref_grid_to_spec(g, s) bind(C, name="ref_grid_to_spec")
+    use iso_c_binding
+    use params, only: mx, nx, ix, il
+    use spectral, only: grid_to_spec
+    real(c_double), intent(in) :: g(ix,il)
+    complex(c_double_complex), intent(out) :: s(mx,nx)
+    s = grid_to_spec(g)
+end subroutine
+
+! spectral.f90:84 laplacian ; :91 inverse_laplacian ; :229 trunct
+subroutine ref_laplacian(a, o) bind(C, name="ref_laplacian")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: laplacian
+    complex(c_double_complex), intent(in) :: a(mx,nx)
+    complex(c_double_complex), intent(out) :: o(mx,nx)
+    o = laplacian(a)
+end subroutine
+
+subroutine ref_inverse_laplacian(a, o) bind(C, name="ref_inverse_laplacian")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: inverse_laplacian
+    complex(c_double_complex), intent(in) :: a(mx,nx)
+    complex(c_double_complex), intent(out) :: o(mx,nx)
+    o = inverse_laplacian(a)
+end subroutine
+
+subroutine ref_trunct(a) bind(C, name="ref_trunct")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: trunct
+    complex(c_double_complex), intent(inout) :: a(mx,nx)
+    call trunct(a)
+end subroutine
+
+! spectral.f90:124 grad ; :146 vds ; :173 uvspec ; :198 vdspec
+subroutine ref_grad(psi, psdx, psdy) bind(C, name="ref_grad")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: grad
+    complex(c_double_complex), intent(inout) :: psi(mx,nx), psdx(mx,nx), psdy(mx,nx)
+    call grad(psi, psdx, psdy)
+end subroutine
+
+subroutine ref_vds(ucosm, vcosm, vorm, divm) bind(C, name="ref_vds")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: vds
+    complex(c_double_complex), intent(inout) :: ucosm(mx,nx), vcosm(mx,nx), vorm(mx,nx), divm(mx,nx)
+    call vds(ucosm, vcosm, vorm, divm)
+end subroutine
+
+subroutine ref_uvspec(vorm, divm, ucosm, vcosm) bind(C, name="ref_uvspec")
+    use iso_c_binding
+    use params, only: mx, nx
+    use spectral, only: uvspec
+    complex(c_double_complex), intent(in) :: vorm(mx,nx), divm(mx,nx)
+    complex(c_double_complex), intent(inout) :: ucosm(mx,nx), vcosm(mx,nx)
+    call uvspec(vorm, divm, ucosm, vcosm)
+end subroutine
+
+subroutine ref_vdspec(ug, vg, vorm, divm, kcos) bind(C, name="ref_vdspec")
+    use iso_c_binding
+    use params, only: mx, nx, ix, il
+    use spectral, only: vdspec
+    real(c_double), intent(in) :: ug(ix,il), vg(ix,il)
+    complex(c_double_complex), intent(out) :: vorm(mx,nx), divm(mx,nx)
+    integer(c_int), value :: kcos
+    call vdspec(ug, vg, vorm, divm, kcos)
+end subroutine
+
+! horizontal_diffusion.f90:36 initialize_horizontal_diffusion ; implicit.f90:36 initialize_implicit
+subroutine ref_tail_init(dt) bind(C, name="ref_tail_init")
+    use iso_c_binding
+    use horizontal_diffusion, only: initialize_horizontal_diffusion
+    use implicit, only: initialize_implicit
+    real(c_double), value :: dt
+    call initialize_horizontal_diffusion
+    call initialize_implicit(dt)
+end subroutine
+
+! horizontal_diffusion.f90:12 public damping tables
+subroutine ref_get_dmp(o_dmp, o_dmpd, o_dmps, o_dmp1, o_dmp1d, o_dmp1s) bind(C, name="ref_get_dmp")
+    use iso_c_binding
+    use params, only: mx, nx
+    use horizontal_diffusion, only: dmp, dmpd, dmps, dmp1, dmp1d, dmp1s
+    real(c_double), intent(out), dimension(mx,nx) :: o_dmp, o_dmpd, o_dmps, o_dmp1, o_dmp1d, o_dmp1s
+    o_dmp = dmp
+    o_dmpd = dmpd
+    o_dmps = dmps
+    o_dmp1 = dmp1
+    o_dmp1d = dmp1d
+    o_dmp1s = dmp1s
+end subroutine
+
+! implicit.f90:11 public reference-temperature profiles
+subroutine ref_get_tref(o_tref, o_tref2, o_tref3) bind(C, name="ref_get_tref")
+    use iso_c_binding
+    use params, only: kx
+    use implicit, only: tref, tref2, tref3
+    real(c_double), intent(out), dimension(kx) :: o_tref, o_tref2, o_tref3
+    o_tref = tref
+    o_tref2 = tref2
+    o_tref3 = tref3
+end subroutine
+
+! horizontal_diffusion.f90:86 / :96 do_horizontal_diffusion (2-D and 3-D specifics)
+subroutine ref_hdiff_2d(field, fdt_in, dmp, dmp1, fdt_out) bind(C, name="ref_hdiff_2d")
+    use iso_c_binding
+    use params, only: mx, nx
+    use horizontal_diffusion, only: do_horizontal_diffusion
+    complex(c_double_complex), intent(in) :: field(mx,nx), fdt_in(mx,nx)
+    real(c_double), intent(in) :: dmp(mx,nx), dmp1(mx,nx)
+    complex(c_double_complex), intent(out) :: fdt_out(mx,nx)
+    fdt_out = do_horizontal_diffusion(field, fdt_in, dmp, dmp1)
+end subroutine
+
+subroutine ref_hdiff_3d(field, fdt_in, dmp, dmp1, fdt_out) bind(C, name="ref_hdiff_3d")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use horizontal_diffusion, only: do_horizontal_diffusion
+    complex(c_double_complex), intent(in) :: field(mx,nx,kx), fdt_in(mx,nx,kx)
+    real(c_double), intent(in) :: dmp(mx,nx), dmp1(mx,nx)
+    complex(c_double_complex), intent(out) :: fdt_out(mx,nx,kx)
+    fdt_out = do_horizontal_diffusion(field, fdt_in, dmp, dmp1)
+end subroutine
+
+! implicit.f90:168 implicit_terms
+subroutine ref_implicit_terms(divdt, tdt, psdt) bind(C, name="ref_implicit_terms")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use implicit, only: implicit_terms
+    complex(c_double_complex), intent(inout) :: divdt(mx,nx,kx), tdt(mx,nx,kx), psdt(mx,nx)
+    call implicit_terms(divdt, tdt, psdt)
+end subroutine
+
+! CPU baseline (bench.py cpu_baseline.kind = "reference"): nrep passes of
+! grid_to_spec followed by spec_to_grid(.,1) over nf independent 2-D fields,
+! one field at a time exactly as the reference executes them (spectral.f90:98-122).
+subroutine ref_roundtrip_loop(nf, nrep, g_in, g_out) bind(C, name="ref_roundtrip_loop")
+    use iso_c_binding
+    use params, only: mx, nx, ix, il
+    use spectral, only: grid_to_spec, spec_to_grid
+    integer(c_int), value :: nf, nrep
+    real(c_double), intent(in) :: g_in(ix,il,nf)
+    real(c_double), intent(out) :: g_out(ix,il,nf)
+    complex(c_double_complex) :: s(mx,nx)
+    integer :: f, r
+    do r = 1, nrep
+        do f = 1, nf
+            s = grid_to_spec(g_in(:,:,f))
+            g_out(:,:,f) = spec_to_grid(s, 1)
+        end do
+    end do
+end subroutine
