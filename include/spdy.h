@@ -1,0 +1,135 @@
+/*
+ * spdy.h -- C ABI of the MI355X-native spectral transform path for speedy.f90.
+ *
+ * This is the drop-in boundary: every entry point below replaces one public procedure of the
+ * reference's Fortran modules `spectral`, `fourier`, `legendre`, `horizontal_diffusion` and
+ * `implicit` (file:line cited per function, relative to /root/reference/source).  The
+ * reference-side binding (an ISO_C_BINDING module that keeps the reference's names and
+ * signatures) is speedy.f90_amd/fortran/spectral.f90; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - All data is FP64.  Arrays are Fortran column-major exactly as the reference declares them:
+ *        grid  g(ix,il)            ix*il doubles, longitude fastest, j=1 southernmost
+ *        spec  s(mx,nx) complex    mx*nx (re,im) pairs, zonal wavenumber index fastest
+ *        four  f(2*mx,il)          re/im interleaved Fourier coefficients per latitude
+ *    A batch of nb fields is nb such arrays back to back (e.g. a (mx,nx,kx) level stack).
+ *  - Functions without suffix take HOST pointers: they copy in, run the HIP kernels, copy out
+ *    and synchronise (signature-compatible with the reference, PCIe-bound).
+ *    Functions ending in _dev take DEVICE pointers, are asynchronous on the plan's stream and
+ *    never touch the host -- this is the throughput path (state stays resident in HBM).
+ *  - Every function returns 0 on success or a negative SPDY_ERR_* code; spdy_last_error()
+ *    gives the message for the calling thread.  There is no CPU fallback: without a usable
+ *    HIP device every compute entry point fails with SPDY_ERR_NO_DEVICE.
+ *  - A plan is immutable after creation (except spdy_implicit_init / spdy_plan_set_stream);
+ *    calls on one plan are serialised by its stream; distinct plans are independent.
+ */
+#ifndef SPDY_H
+#define SPDY_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spdy_plan spdy_plan;
+
+enum {
+    SPDY_OK = 0,
+    SPDY_ERR_ARG = -1,          /* bad argument (null pointer, nb > max_batch, bad kcos ...)   */
+    SPDY_ERR_UNSUPPORTED = -2,  /* resolution the kernels are not built for                   */
+    SPDY_ERR_NO_DEVICE = -3,    /* no HIP device / host-only plan used for compute             */
+    SPDY_ERR_HIP = -4,          /* a HIP runtime call failed                                  */
+    SPDY_ERR_STATE = -5,        /* e.g. implicit_terms before implicit_init                    */
+    SPDY_ERR_TABLE = -6         /* generated table failed its pinned-value self check          */
+};
+
+/* ---- plan ------------------------------------------------------------------------------
+ * Replaces the private module state filled by initialize_geometry (geometry.f90:35),
+ * initialize_fourier (fourier.f90:18), initialize_legendre (legendre.f90:23),
+ * initialize_spectral (spectral.f90:20) and initialize_horizontal_diffusion
+ * (horizontal_diffusion.f90:36).  Supported: (trunc,ix,iy) = (30,96,24) and (63,192,48);
+ * kx in {5,7,8} for the implicit solve (geometry.f90:42-48), any kx >= 1 otherwise.
+ * device >= 0 selects a HIP device; device = -1 builds a host-only plan (tables only: lets
+ * CPU-side tests inspect tables; every compute call on it returns SPDY_ERR_NO_DEVICE).
+ * max_batch bounds nb of every batched call (sizes the Fourier workspace).                 */
+int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan);
+int spdy_plan_destroy(spdy_plan *plan);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the plan's own. */
+int spdy_plan_set_stream(spdy_plan *plan, void *hip_stream);
+int spdy_plan_synchronize(spdy_plan *plan);
+/* Per-kernel timing for the roofline report: while on, every transform kernel launched by the
+ * *_dev entry points is bracketed by HIP events on its own stream.  spdy_plan_get_profile
+ * synchronises, adds up milliseconds and launch counts per kernel kind (arrays of
+ * SPDY_K_COUNT) and clears the record.                                                       */
+enum { SPDY_K_LEGENDRE_INV = 0, SPDY_K_FOURIER_INV = 1, SPDY_K_FOURIER_DIR = 2, SPDY_K_LEGENDRE_DIR = 3,
+       SPDY_K_COUNT = 4 };
+int spdy_plan_set_profiling(spdy_plan *plan, int on);
+int spdy_plan_get_profile(spdy_plan *plan, double *ms, int *launches);
+/* dims[0..7] = trunc, ix, iy, il, kx, nx, mx, max_batch */
+int spdy_plan_dims(const spdy_plan *plan, int *dims);
+const char *spdy_last_error(void);
+/* Copy a named host table into buf (up to cap doubles); returns the element count or <0.
+ * Names: sia_half coa_half cosgr cosgr2 hsg dhs fsg dhsr fsgr work ifac epsi wt poly nsh2
+ *        el2 elm2 el4 trfilt gradx gradym gradyp uvdx uvdym uvdyp vddym vddyp
+ *        dmp dmpd dmps dmp1 dmp1d dmp1s tref tref1 tref2 tref3 xc xd xj dhsx elz          */
+int spdy_get_table(const spdy_plan *plan, const char *name, double *buf, int cap);
+
+/* ---- grid <-> spectral transforms --------------------------------------------------------
+ * spec_to_grid(vorm,kcos)  spectral.f90:98-110  = fourier_inv(legendre_inv(.),kcos)
+ * grid_to_spec(vorg)       spectral.f90:112-122 = legendre_dir(fourier_dir(.))
+ * kcos semantics as fourier.f90:47-51: 1 = plain, anything else = multiply row j by cosgr(j). */
+int spdy_spec_to_grid(spdy_plan *plan, const double *spec, int kcos, double *grid);
+int spdy_grid_to_spec(spdy_plan *plan, const double *grid, double *spec);
+/* nb independent fields; kcos[nb] per field (NULL = all 1). */
+int spdy_spec_to_grid_batch(spdy_plan *plan, int nb, const double *spec, const int *kcos, double *grid);
+int spdy_grid_to_spec_batch(spdy_plan *plan, int nb, const double *grid, double *spec);
+/* Device-resident batch.  d_kcos: device int[nb] or NULL (then kcos_all applies to every field). */
+int spdy_spec_to_grid_dev(spdy_plan *plan, int nb, const double *d_spec, const int *d_kcos, int kcos_all,
+                          double *d_grid);
+int spdy_grid_to_spec_dev(spdy_plan *plan, int nb, const double *d_grid, double *d_spec);
+
+/* ---- transform stages (host pointers, batched) -------------------------------------------
+ * legendre_inv legendre.f90:74-111 ; legendre_dir legendre.f90:114-155
+ * fourier_inv  fourier.f90:23-53   ; fourier_dir  fourier.f90:56-82                          */
+int spdy_legendre_inv(spdy_plan *plan, int nb, const double *spec, double *four);
+int spdy_legendre_dir(spdy_plan *plan, int nb, const double *four, double *spec);
+int spdy_fourier_inv(spdy_plan *plan, int nb, const double *four, int kcos, double *grid);
+int spdy_fourier_dir(spdy_plan *plan, int nb, const double *grid, double *four);
+
+/* ---- spectral-space operators (nb fields each) -------------------------------------------
+ * laplacian spectral.f90:84 ; inverse_laplacian :91 ; trunct :229 (in place)
+ * grad :124 ; vds :146 ; uvspec :173 ; vdspec :198 (kcos==2: *cosgr, else *cosgr2)            */
+int spdy_laplacian(spdy_plan *plan, int nb, const double *in, double *out);
+int spdy_inverse_laplacian(spdy_plan *plan, int nb, const double *in, double *out);
+int spdy_trunct(spdy_plan *plan, int nb, double *inout);
+int spdy_grad(spdy_plan *plan, int nb, const double *psi, double *psdx, double *psdy);
+int spdy_vds(spdy_plan *plan, int nb, const double *ucosm, const double *vcosm, double *vorm, double *divm);
+int spdy_uvspec(spdy_plan *plan, int nb, const double *vorm, const double *divm, double *ucosm, double *vcosm);
+int spdy_vdspec(spdy_plan *plan, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos);
+int spdy_laplacian_dev(spdy_plan *plan, int nb, const double *in, double *out);
+int spdy_inverse_laplacian_dev(spdy_plan *plan, int nb, const double *in, double *out);
+int spdy_trunct_dev(spdy_plan *plan, int nb, double *inout);
+int spdy_grad_dev(spdy_plan *plan, int nb, const double *psi, double *psdx, double *psdy);
+int spdy_vds_dev(spdy_plan *plan, int nb, const double *ucosm, const double *vcosm, double *vorm, double *divm);
+int spdy_uvspec_dev(spdy_plan *plan, int nb, const double *vorm, const double *divm, double *ucosm, double *vcosm);
+int spdy_vdspec_dev(spdy_plan *plan, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos);
+
+/* ---- spectral-space tail ------------------------------------------------------------------
+ * do_horizontal_diffusion(field,fdt_in,dmp,dmp1) horizontal_diffusion.f90:86-105:
+ *     fdt_out = (fdt_in - dmp*field)*dmp1, nlev levels sharing the two (mx,nx) real tables.
+ * initialize_implicit(dt) implicit.f90:36-165 ; implicit_terms(divdt,tdt,psdt) :168-217
+ * (in place; divdt,tdt are (mx,nx,kx), psdt is (mx,nx)).                                      */
+int spdy_hdiff(spdy_plan *plan, int nlev, const double *field, const double *fdt_in, const double *dmp,
+               const double *dmp1, double *fdt_out);
+int spdy_hdiff_dev(spdy_plan *plan, int nlev, const double *field, const double *fdt_in, const double *d_dmp,
+                   const double *d_dmp1, double *fdt_out);
+int spdy_implicit_init(spdy_plan *plan, double dt);
+int spdy_implicit_terms(spdy_plan *plan, double *divdt, double *tdt, double *psdt);
+int spdy_implicit_terms_dev(spdy_plan *plan, double *divdt, double *tdt, double *psdt);
+/* Device copies of the plan's damping tables for spdy_hdiff_dev: name in
+ * {dmp,dmpd,dmps,dmp1,dmp1d,dmp1s}; *d_ptr stays valid until the next spdy_implicit_init.     */
+int spdy_device_table(spdy_plan *plan, const char *name, const double **d_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPDY_H */

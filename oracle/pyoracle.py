@@ -72,7 +72,7 @@ class Oracle(_Dims):
             self.ctx = None
 
     def table(self, name):
-        n = self.lib.orc_get_table(self.ctx, name.encode(), None) if name not in ("ifac", "nsh2") else 64
+        n = self.lib.orc_get_table(self.ctx, name.encode(), None) if name not in ("ifac", "nsh2") else max(15, self.nx)
         if n < 0:
             raise KeyError(name)
         out = np.zeros(n)

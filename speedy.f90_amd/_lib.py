@@ -1,0 +1,96 @@
+"""ctypes loader for libspdy.so (the C-ABI declared in include/spdy.h).
+
+There is no Python/NumPy fallback: if the HIP library is missing or no device is usable the
+caller gets an exception, never a silently slower path.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libspdy.so")
+
+c_void_p, c_int, c_double, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p
+
+# name -> argtypes (restype is int everywhere except spdy_last_error)
+SIGNATURES = {
+    "spdy_plan_create": [c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)],
+    "spdy_plan_destroy": [c_void_p],
+    "spdy_plan_set_stream": [c_void_p, c_void_p],
+    "spdy_plan_synchronize": [c_void_p],
+    "spdy_plan_dims": [c_void_p, ctypes.POINTER(c_int)],
+    "spdy_plan_set_profiling": [c_void_p, c_int],
+    "spdy_plan_get_profile": [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int)],
+    "spdy_get_table": [c_void_p, c_char_p, c_void_p, c_int],
+    "spdy_spec_to_grid": [c_void_p, c_void_p, c_int, c_void_p],
+    "spdy_grid_to_spec": [c_void_p, c_void_p, c_void_p],
+    "spdy_spec_to_grid_batch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "spdy_grid_to_spec_batch": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_spec_to_grid_dev": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "spdy_grid_to_spec_dev": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_legendre_inv": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_legendre_dir": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_fourier_inv": [c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "spdy_fourier_dir": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_laplacian": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_inverse_laplacian": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_trunct": [c_void_p, c_int, c_void_p],
+    "spdy_grad": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "spdy_vds": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_uvspec": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_vdspec": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "spdy_laplacian_dev": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_inverse_laplacian_dev": [c_void_p, c_int, c_void_p, c_void_p],
+    "spdy_trunct_dev": [c_void_p, c_int, c_void_p],
+    "spdy_grad_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "spdy_vds_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_uvspec_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_vdspec_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "spdy_hdiff": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_hdiff_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_implicit_init": [c_void_p, c_double],
+    "spdy_implicit_terms": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_implicit_terms_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_device_table": [c_void_p, c_char_p, ctypes.POINTER(c_void_p)],
+}
+
+
+class SpdyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("spdy error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile libspdy.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", HERE, "all"], stdout=out)
+
+
+_lib = None
+
+
+def load():
+    """Load libspdy.so and bind every symbol include/spdy.h declares.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the transform path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.spdy_last_error.argtypes = []
+    lib.spdy_last_error.restype = c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise SpdyError(rc, load().spdy_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,676 @@
+// C ABI (include/spdy.h) over the gfx950 kernels: plan management, table upload, host-pointer
+// drop-ins and device-pointer batched entry points.  No CPU compute path exists here: a plan
+// without a device can only report its tables.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spdy.h"
+#include "spdy_kernels.hpp"
+#include "spdy_tables.hpp"
+
+using spdy::DevPlan;
+using spdy::HostTables;
+
+struct spdy_plan {
+    HostTables tab;
+    int max_batch = 0;
+    int device = -1;
+    DevPlan dev{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<void *> allocs;       // everything hipMalloc'ed for this plan
+    double *four = nullptr;           // [max_batch][il][fs] Fourier workspace
+    double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;  // host-API staging
+    size_t stage_elems = 0;
+    int *d_kcos = nullptr;
+    // device copies of dt-dependent tables
+    double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
+    // optional per-kernel timing (HIP events on the launch stream)
+    bool profiling = false;
+    struct Span { int kind; hipEvent_t t0, t1; };
+    std::vector<Span> spans;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(SPDY_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_PLAN(p)                                                                   \
+    do {                                                                               \
+        if (!(p)) return fail(SPDY_ERR_ARG, "null plan");                              \
+    } while (0)
+#define NEED_DEVICE(p)                                                                                       \
+    do {                                                                                                     \
+        NEED_PLAN(p);                                                                                        \
+        if ((p)->device < 0) return fail(SPDY_ERR_NO_DEVICE, "host-only plan: no HIP device, no CPU fallback"); \
+        HIP_TRY(hipSetDevice((p)->device));                                                                  \
+    } while (0)
+
+int dev_alloc(spdy_plan *p, size_t bytes, void **out)
+{
+    void *ptr = nullptr;
+    HIP_TRY(hipMalloc(&ptr, bytes ? bytes : 8));
+    p->allocs.push_back(ptr);
+    *out = ptr;
+    return SPDY_OK;
+}
+
+int dev_upload(spdy_plan *p, const std::vector<double> &v, const double **out)
+{
+    void *ptr = nullptr;
+    int rc = dev_alloc(p, v.size() * sizeof(double), &ptr);
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpy(ptr, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    *out = static_cast<const double *>(ptr);
+    return SPDY_OK;
+}
+
+// MFMA A-operand images of the Legendre table (v_mfma_f64_16x16x4_f64: lane l supplies
+// A[row = l & 15][k = l >> 4]); zero padded so ragged edges need no masking in the kernel.
+void build_mfma_tables(const HostTables &t, int ks_inv, int jt, int nt_dir, int js_dir,
+                       std::vector<double> &inv, std::vector<double> &dir)
+{
+    const int mx = t.mx, nx = t.nx, iy = t.iy;
+    auto P = [&](int m, int n, int j) { return t.poly[m + mx * (n + (size_t)nx * j)]; };
+    inv.assign((size_t)mx * 2 * ks_inv * jt * 64, 0.0);
+    dir.assign((size_t)mx * 2 * nt_dir * js_dir * 64, 0.0);
+    for (int m = 0; m < mx; ++m)
+        for (int par = 0; par < 2; ++par) {
+            // inverse (legendre.f90:92-103): rows = latitudes, k = n of this parity with m+n <= trunc+1
+            for (int ks = 0; ks < ks_inv; ++ks)
+                for (int tt = 0; tt < jt; ++tt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int j = 16 * tt + (lane & 15), n = 2 * (4 * ks + (lane >> 4)) + par;
+                        double v = 0.0;
+                        if (j < iy && n < nx && m + n <= t.trunc + 1) v = P(m, n, j);
+                        inv[((((size_t)m * 2 + par) * ks_inv + ks) * jt + tt) * 64 + lane] = v;
+                    }
+            // direct (legendre.f90:142-154): rows = n of this parity with n <= trunc and m+n <= trunc+1,
+            // k = latitude; Gaussian weight folded in (legendre.f90:131-132)
+            for (int tt = 0; tt < nt_dir; ++tt)
+                for (int ks = 0; ks < js_dir; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = 2 * (16 * tt + (lane & 15)) + par, j = 4 * ks + (lane >> 4);
+                        double v = 0.0;
+                        if (j < iy && n <= t.trunc && m + n <= t.trunc + 1) v = P(m, n, j) * t.wt[j];
+                        dir[((((size_t)m * 2 + par) * nt_dir + tt) * js_dir + ks) * 64 + lane] = v;
+                    }
+        }
+}
+
+int upload_all(spdy_plan *p)
+{
+    HostTables &t = p->tab;
+    DevPlan &d = p->dev;
+    d.trunc = t.trunc; d.ix = t.ix; d.iy = t.iy; d.il = t.il; d.kx = t.kx; d.nx = t.nx; d.mx = t.mx;
+    d.fs = (2 * t.mx + 15) / 16 * 16;
+    d.ks_inv = ((t.nx + 1) / 2 + 3) / 4;
+    d.jt = (t.iy + 15) / 16;
+    d.nt_dir = ((t.nx + 1) / 2 + 15) / 16;
+    d.js_dir = t.iy / 4;
+    std::vector<double> inv, dir;
+    build_mfma_tables(t, d.ks_inv, d.jt, d.nt_dir, d.js_dir, inv, dir);
+    int rc;
+#define UP(vec, field) if ((rc = dev_upload(p, vec, &d.field))) return rc
+    UP(inv, pa_inv); UP(dir, pa_dir); UP(t.cosgr, cosgr); UP(t.cosgr2, cosgr2);
+    UP(t.el2, el2); UP(t.elm2, elm2); UP(t.trfilt, trfilt); UP(t.gradx, gradx); UP(t.gradym, gradym);
+    UP(t.gradyp, gradyp); UP(t.uvdx, uvdx); UP(t.uvdym, uvdym); UP(t.uvdyp, uvdyp); UP(t.vddym, vddym);
+    UP(t.vddyp, vddyp);
+#undef UP
+    // FFT constants: FFTPACK `work` split by stage (fftpack.f90:45-66 layout)
+    spdy::FftConstants fc;
+    std::memset(&fc, 0, sizeof(fc));
+    const int nfirst = (t.ifac[2] - 1) * 48;              // ido=48 stage: (ip-1) blocks of 48
+    for (int i = 0; i < nfirst; ++i) fc.first[i] = t.work[i];
+    for (int i = 0; i < 36; ++i) fc.a[i] = t.work[nfirst + i];
+    for (int i = 0; i < 9; ++i) fc.b[i] = t.work[nfirst + 36 + i];
+    fc.taui = t.taui; fc.sqrt2 = t.sqrt2; fc.hsqt2 = t.hsqt2; fc.scale = t.fwd_scale;
+    HIP_TRY(spdy::upload_fft_constants(t.ix, fc));
+
+    const size_t four_elems = (size_t)p->max_batch * t.il * d.fs;
+    void *ptr;
+    if ((rc = dev_alloc(p, four_elems * sizeof(double), &ptr))) return rc;
+    p->four = static_cast<double *>(ptr);
+    HIP_TRY(hipMemset(p->four, 0, four_elems * sizeof(double)));
+    // staging for the host-pointer API: four buffers big enough for max_batch grids (the largest array kind)
+    p->stage_elems = (size_t)p->max_batch * t.il * t.ix;
+    double **stages[4] = {&p->stage_a, &p->stage_b, &p->stage_c, &p->stage_d};
+    for (auto s : stages) {
+        if ((rc = dev_alloc(p, p->stage_elems * sizeof(double), &ptr))) return rc;
+        *s = static_cast<double *>(ptr);
+    }
+    if ((rc = dev_alloc(p, sizeof(int) * (size_t)p->max_batch, &ptr))) return rc;
+    p->d_kcos = static_cast<int *>(ptr);
+    for (int i = 0; i < 6; ++i) {
+        if ((rc = dev_alloc(p, sizeof(double) * t.mx * t.nx, &ptr))) return rc;
+        p->d_dmp[i] = static_cast<double *>(ptr);
+    }
+    const std::vector<double> *src[3] = {&t.dmp, &t.dmpd, &t.dmps};
+    for (int i = 0; i < 3; ++i)
+        HIP_TRY(hipMemcpy(p->d_dmp[i], src[i]->data(), sizeof(double) * t.mx * t.nx, hipMemcpyHostToDevice));
+    const int kx = t.kx;
+    struct { double **dst; size_t n; } imp[6] = {{&p->d_xd, (size_t)kx * kx}, {&p->d_xc, (size_t)kx * kx},
+                                                 {&p->d_xj, (size_t)kx * kx * (t.mx + t.nx + 1)},
+                                                 {&p->d_tref1, (size_t)kx}, {&p->d_dhsx, (size_t)kx},
+                                                 {&p->d_elz, (size_t)t.mx * t.nx}};
+    for (auto &e : imp) {
+        if ((rc = dev_alloc(p, e.n * sizeof(double), &ptr))) return rc;
+        *e.dst = static_cast<double *>(ptr);
+    }
+    d.xd = p->d_xd; d.xc = p->d_xc; d.xj = p->d_xj; d.tref1 = p->d_tref1; d.dhsx = p->d_dhsx; d.elz = p->d_elz;
+    return SPDY_OK;
+}
+
+inline size_t spec_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.nx; }
+inline size_t grid_elems(const spdy_plan *p) { return (size_t)p->tab.ix * p->tab.il; }
+inline size_t four_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.il; }
+
+int check_batch(const spdy_plan *p, int nb)
+{
+    if (nb < 0 || nb > p->max_batch) return fail(SPDY_ERR_ARG, "nb=%d outside [0, max_batch=%d]", nb, p->max_batch);
+    return SPDY_OK;
+}
+
+int h2d(spdy_plan *p, double *dst, const double *src, size_t n)
+{
+    if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    return SPDY_OK;
+}
+int d2h(spdy_plan *p, double *dst, const double *src, size_t n)
+{
+    if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    return SPDY_OK;
+}
+// Fourier workspace rows are fs doubles apart; the reference layout packs 2*mx per row.
+int four_to_host(spdy_plan *p, double *dst, int nb)
+{
+    const size_t w = 2 * (size_t)p->tab.mx * sizeof(double);
+    if (nb) HIP_TRY(hipMemcpy2DAsync(dst, w, p->four, p->dev.fs * sizeof(double), w, (size_t)nb * p->tab.il,
+                                     hipMemcpyDeviceToHost, p->stream));
+    return SPDY_OK;
+}
+int four_from_host(spdy_plan *p, const double *src, int nb)
+{
+    const size_t w = 2 * (size_t)p->tab.mx * sizeof(double);
+    if (nb) HIP_TRY(hipMemcpy2DAsync(p->four, p->dev.fs * sizeof(double), src, w, w, (size_t)nb * p->tab.il,
+                                     hipMemcpyHostToDevice, p->stream));
+    return SPDY_OK;
+}
+int sync(spdy_plan *p)
+{
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SPDY_OK;
+}
+
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define KERNEL(expr) HIP_TRY(expr)
+
+// Launch one transform kernel; when profiling is on, bracket it with HIP events recorded on
+// the very stream it runs on (kind: SPDY_K_*).
+template <class F> int timed(spdy_plan *p, int kind, F &&launch)
+{
+    if (!p->profiling) { HIP_TRY(launch()); return SPDY_OK; }
+    spdy_plan::Span sp{kind, nullptr, nullptr};
+    HIP_TRY(hipEventCreate(&sp.t0));
+    HIP_TRY(hipEventCreate(&sp.t1));
+    HIP_TRY(hipEventRecord(sp.t0, p->stream));
+    HIP_TRY(launch());
+    HIP_TRY(hipEventRecord(sp.t1, p->stream));
+    p->spans.push_back(sp);
+    return SPDY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *spdy_last_error(void) { return g_err.c_str(); }
+
+int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan)
+{
+    if (!plan) return fail(SPDY_ERR_ARG, "null plan pointer");
+    *plan = nullptr;
+    if (max_batch < 1) return fail(SPDY_ERR_ARG, "max_batch must be >= 1");
+    if (!((trunc == 30 && ix == 96 && iy == 24) || (trunc == 63 && ix == 192 && iy == 48)))
+        return fail(SPDY_ERR_UNSUPPORTED, "kernels are built for T30 (96x48) and T63 (192x96); got trunc=%d ix=%d iy=%d",
+                    trunc, ix, iy);
+    if (kx < 1 || kx > 8) return fail(SPDY_ERR_UNSUPPORTED, "kx=%d outside 1..8", kx);
+    spdy_plan *p = new spdy_plan;
+    const std::string err = p->tab.build(trunc, ix, iy, kx);
+    if (!err.empty()) {
+        delete p;
+        return fail(SPDY_ERR_TABLE, "table generation: %s", err.c_str());
+    }
+    p->max_batch = max_batch;
+    p->device = device;
+    if (device >= 0) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || device >= ndev) {
+            delete p;
+            return fail(SPDY_ERR_NO_DEVICE, "HIP device %d not available (%s, %d visible); there is no CPU fallback",
+                        device, hipGetErrorString(e), ndev);
+        }
+        int rc = SPDY_OK;
+        if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&p->own_stream)) != hipSuccess)
+            rc = fail(SPDY_ERR_HIP, "device init: %s", hipGetErrorString(e));
+        p->stream = p->own_stream;
+        if (!rc) rc = upload_all(p);
+        if (rc) {
+            const std::string keep = g_err;
+            spdy_plan_destroy(p);
+            g_err = keep;
+            return rc;
+        }
+    }
+    *plan = p;
+    return SPDY_OK;
+}
+
+int spdy_plan_destroy(spdy_plan *p)
+{
+    if (!p) return SPDY_OK;
+    if (p->device >= 0) {
+        (void)hipSetDevice(p->device);
+        if (p->stream) (void)hipStreamSynchronize(p->stream);
+        for (void *a : p->allocs) (void)hipFree(a);
+        if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    }
+    delete p;
+    return SPDY_OK;
+}
+
+int spdy_plan_set_stream(spdy_plan *p, void *hip_stream)
+{
+    NEED_DEVICE(p);
+    p->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->own_stream;
+    return SPDY_OK;
+}
+
+int spdy_plan_synchronize(spdy_plan *p)
+{
+    NEED_DEVICE(p);
+    return sync(p);
+}
+
+int spdy_plan_set_profiling(spdy_plan *p, int on)
+{
+    NEED_DEVICE(p);
+    p->profiling = on != 0;
+    return SPDY_OK;
+}
+
+int spdy_plan_get_profile(spdy_plan *p, double *ms, int *launches)
+{
+    NEED_DEVICE(p);
+    if (!ms || !launches) return fail(SPDY_ERR_ARG, "null output");
+    for (int k = 0; k < SPDY_K_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (auto &sp : p->spans) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.t0, sp.t1));
+        ms[sp.kind] += t;
+        launches[sp.kind] += 1;
+        (void)hipEventDestroy(sp.t0);
+        (void)hipEventDestroy(sp.t1);
+    }
+    p->spans.clear();
+    return SPDY_OK;
+}
+
+int spdy_plan_dims(const spdy_plan *p, int *dims)
+{
+    NEED_PLAN(p);
+    if (!dims) return fail(SPDY_ERR_ARG, "null dims");
+    const HostTables &t = p->tab;
+    const int v[8] = {t.trunc, t.ix, t.iy, t.il, t.kx, t.nx, t.mx, p->max_batch};
+    std::memcpy(dims, v, sizeof(v));
+    return SPDY_OK;
+}
+
+int spdy_get_table(const spdy_plan *p, const char *name, double *buf, int cap)
+{
+    NEED_PLAN(p);
+    if (!name) return fail(SPDY_ERR_ARG, "null table name");
+    std::vector<double> scratch;
+    int n = 0;
+    const double *src = p->tab.lookup(name, &n, scratch);
+    if (!src) return fail(SPDY_ERR_ARG, "unknown table '%s'", name);
+    if (buf) std::memcpy(buf, src, sizeof(double) * (size_t)(n < cap ? n : cap));
+    return n;
+}
+
+/* ---------------------------------------------------------------- transforms, device pointers */
+int spdy_spec_to_grid_dev(spdy_plan *p, int nb, const double *d_spec, const int *d_kcos, int kcos_all, double *d_grid)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
+    RC(timed(p, SPDY_K_LEGENDRE_INV, [&] { return spdy::launch_legendre_inv(p->dev, nb, d_spec, p->four, p->stream); }));
+    RC(timed(p, SPDY_K_FOURIER_INV, [&] { return spdy::launch_fourier_inv(p->dev, nb, p->four, d_kcos, kcos_all, d_grid, p->stream); }));
+    return SPDY_OK;
+}
+
+int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_spec)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
+    RC(timed(p, SPDY_K_FOURIER_DIR, [&] { return spdy::launch_fourier_dir(p->dev, nb, d_grid, nullptr, p->four, p->stream); }));
+    RC(timed(p, SPDY_K_LEGENDRE_DIR, [&] { return spdy::launch_legendre_dir(p->dev, nb, p->four, d_spec, p->stream); }));
+    return SPDY_OK;
+}
+
+/* ---------------------------------------------------------------- transforms, host pointers */
+int spdy_spec_to_grid_batch(spdy_plan *p, int nb, const double *spec, const int *kcos, double *grid)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!spec || !grid)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, spec, nb * spec_elems(p)));
+    if (kcos && nb) HIP_TRY(hipMemcpyAsync(p->d_kcos, kcos, sizeof(int) * nb, hipMemcpyHostToDevice, p->stream));
+    RC(spdy_spec_to_grid_dev(p, nb, p->stage_a, kcos ? p->d_kcos : nullptr, 1, p->stage_b));
+    RC(d2h(p, grid, p->stage_b, nb * grid_elems(p)));
+    return sync(p);
+}
+
+int spdy_grid_to_spec_batch(spdy_plan *p, int nb, const double *grid, double *spec)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!spec || !grid)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, grid, nb * grid_elems(p)));
+    RC(spdy_grid_to_spec_dev(p, nb, p->stage_a, p->stage_b));
+    RC(d2h(p, spec, p->stage_b, nb * spec_elems(p)));
+    return sync(p);
+}
+
+int spdy_spec_to_grid(spdy_plan *p, const double *spec, int kcos, double *grid)
+{
+    return spdy_spec_to_grid_batch(p, 1, spec, &kcos, grid);
+}
+
+int spdy_grid_to_spec(spdy_plan *p, const double *grid, double *spec)
+{
+    return spdy_grid_to_spec_batch(p, 1, grid, spec);
+}
+
+/* ---------------------------------------------------------------- stages, host pointers */
+int spdy_legendre_inv(spdy_plan *p, int nb, const double *spec, double *four)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!spec || !four)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, spec, nb * spec_elems(p)));
+    KERNEL(spdy::launch_legendre_inv(p->dev, nb, p->stage_a, p->four, p->stream));
+    RC(four_to_host(p, four, nb));
+    RC(sync(p));
+    // Im(m'=0) is produced as an exact 0 +/- 0 by the contraction; nothing to fix up.
+    return SPDY_OK;
+}
+
+int spdy_legendre_dir(spdy_plan *p, int nb, const double *four, double *spec)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!spec || !four)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(four_from_host(p, four, nb));
+    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_a, p->stream));
+    RC(d2h(p, spec, p->stage_a, nb * spec_elems(p)));
+    return sync(p);
+}
+
+int spdy_fourier_inv(spdy_plan *p, int nb, const double *four, int kcos, double *grid)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!grid || !four)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(four_from_host(p, four, nb));
+    KERNEL(spdy::launch_fourier_inv(p->dev, nb, p->four, nullptr, kcos, p->stage_a, p->stream));
+    RC(d2h(p, grid, p->stage_a, nb * grid_elems(p)));
+    return sync(p);
+}
+
+int spdy_fourier_dir(spdy_plan *p, int nb, const double *grid, double *four)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!grid || !four)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, grid, nb * grid_elems(p)));
+    KERNEL(spdy::launch_fourier_dir(p->dev, nb, p->stage_a, nullptr, p->four, p->stream));
+    RC(four_to_host(p, four, nb));
+    return sync(p);
+}
+
+/* ---------------------------------------------------------------- spectral operators */
+int spdy_laplacian_dev(spdy_plan *p, int nb, const double *in, double *out)
+{
+    NEED_DEVICE(p);
+    KERNEL(spdy::launch_scale_op(p->dev, spdy::OP_LAPLACIAN, nb, in, out, p->stream));
+    return SPDY_OK;
+}
+int spdy_inverse_laplacian_dev(spdy_plan *p, int nb, const double *in, double *out)
+{
+    NEED_DEVICE(p);
+    KERNEL(spdy::launch_scale_op(p->dev, spdy::OP_INV_LAPLACIAN, nb, in, out, p->stream));
+    return SPDY_OK;
+}
+int spdy_trunct_dev(spdy_plan *p, int nb, double *inout)
+{
+    NEED_DEVICE(p);
+    KERNEL(spdy::launch_scale_op(p->dev, spdy::OP_TRUNCT, nb, inout, inout, p->stream));
+    return SPDY_OK;
+}
+int spdy_grad_dev(spdy_plan *p, int nb, const double *psi, double *psdx, double *psdy)
+{
+    NEED_DEVICE(p);
+    KERNEL(spdy::launch_grad(p->dev, nb, psi, psdx, psdy, p->stream));
+    return SPDY_OK;
+}
+int spdy_vds_dev(spdy_plan *p, int nb, const double *u, const double *v, double *vor, double *dv)
+{
+    NEED_DEVICE(p);
+    KERNEL(spdy::launch_vds(p->dev, nb, u, v, vor, dv, p->stream));
+    return SPDY_OK;
+}
+int spdy_uvspec_dev(spdy_plan *p, int nb, const double *vor, const double *dv, double *u, double *v)
+{
+    NEED_DEVICE(p);
+    KERNEL(spdy::launch_uvspec(p->dev, nb, vor, dv, u, v, p->stream));
+    return SPDY_OK;
+}
+/* vdspec: scale on load, two direct transforms, then vds.  Uses stage_c/stage_d as the two
+ * intermediate spectra, so ug/vg/vorm/divm may be the caller's own device buffers.            */
+int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
+    KERNEL(spdy::launch_fourier_dir(p->dev, nb, ug, sc, p->four, p->stream));
+    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_c, p->stream));
+    KERNEL(spdy::launch_fourier_dir(p->dev, nb, vg, sc, p->four, p->stream));
+    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_d, p->stream));
+    KERNEL(spdy::launch_vds(p->dev, nb, p->stage_c, p->stage_d, vorm, divm, p->stream));
+    return SPDY_OK;
+}
+
+#define HOST_1IN_1OUT(name, devfn)                                                 \
+    int name(spdy_plan *p, int nb, const double *in, double *out)                  \
+    {                                                                              \
+        NEED_DEVICE(p);                                                            \
+        RC(check_batch(p, nb));                                                    \
+        if (nb && (!in || !out)) return fail(SPDY_ERR_ARG, "null pointer");        \
+        RC(h2d(p, p->stage_a, in, nb * spec_elems(p)));                            \
+        RC(devfn(p, nb, p->stage_a, p->stage_b));                                  \
+        RC(d2h(p, out, p->stage_b, nb * spec_elems(p)));                           \
+        return sync(p);                                                            \
+    }
+HOST_1IN_1OUT(spdy_laplacian, spdy_laplacian_dev)
+HOST_1IN_1OUT(spdy_inverse_laplacian, spdy_inverse_laplacian_dev)
+
+int spdy_trunct(spdy_plan *p, int nb, double *inout)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && !inout) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, inout, nb * spec_elems(p)));
+    RC(spdy_trunct_dev(p, nb, p->stage_a));
+    RC(d2h(p, inout, p->stage_a, nb * spec_elems(p)));
+    return sync(p);
+}
+
+int spdy_grad(spdy_plan *p, int nb, const double *psi, double *psdx, double *psdy)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!psi || !psdx || !psdy)) return fail(SPDY_ERR_ARG, "null pointer");
+    const size_t n = nb * spec_elems(p);
+    RC(h2d(p, p->stage_a, psi, n));
+    // rows of psdy the reference leaves untouched keep the caller's values
+    RC(h2d(p, p->stage_c, psdy, n));
+    RC(spdy_grad_dev(p, nb, p->stage_a, p->stage_b, p->stage_c));
+    RC(d2h(p, psdx, p->stage_b, n));
+    RC(d2h(p, psdy, p->stage_c, n));
+    return sync(p);
+}
+
+#define HOST_2IN_2OUT(name, devfn)                                                                   \
+    int name(spdy_plan *p, int nb, const double *a, const double *b, double *c, double *d)           \
+    {                                                                                                \
+        NEED_DEVICE(p);                                                                              \
+        RC(check_batch(p, nb));                                                                      \
+        if (nb && (!a || !b || !c || !d)) return fail(SPDY_ERR_ARG, "null pointer");                 \
+        const size_t n = nb * spec_elems(p);                                                         \
+        RC(h2d(p, p->stage_a, a, n));                                                                \
+        RC(h2d(p, p->stage_b, b, n));                                                                \
+        RC(h2d(p, p->stage_c, c, n)); /* untouched entries keep the caller's values */              \
+        RC(h2d(p, p->stage_d, d, n));                                                                \
+        RC(devfn(p, nb, p->stage_a, p->stage_b, p->stage_c, p->stage_d));                            \
+        RC(d2h(p, c, p->stage_c, n));                                                                \
+        RC(d2h(p, d, p->stage_d, n));                                                                \
+        return sync(p);                                                                              \
+    }
+HOST_2IN_2OUT(spdy_vds, spdy_vds_dev)
+HOST_2IN_2OUT(spdy_uvspec, spdy_uvspec_dev)
+
+int spdy_vdspec(spdy_plan *p, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!ug || !vg || !vorm || !divm)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, ug, nb * grid_elems(p)));
+    RC(h2d(p, p->stage_b, vg, nb * grid_elems(p)));
+    // outputs land in the tails of stage_a/b only after both grids are consumed: use the Fourier
+    // workspace-independent spectra buffers stage_c/d inside, then vds writes into stage_a/b.
+    RC(spdy_vdspec_dev(p, nb, p->stage_a, p->stage_b, p->stage_a, p->stage_b, kcos));
+    RC(d2h(p, vorm, p->stage_a, nb * spec_elems(p)));
+    RC(d2h(p, divm, p->stage_b, nb * spec_elems(p)));
+    return sync(p);
+}
+
+/* ---------------------------------------------------------------- spectral-space tail */
+int spdy_hdiff_dev(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *d_dmp,
+                   const double *d_dmp1, double *fdt_out)
+{
+    NEED_DEVICE(p);
+    if (nlev < 0) return fail(SPDY_ERR_ARG, "nlev < 0");
+    KERNEL(spdy::launch_hdiff(p->dev, nlev, field, fdt_in, d_dmp, d_dmp1, fdt_out, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_hdiff(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *dmp,
+               const double *dmp1, double *fdt_out)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nlev));
+    if (nlev && (!field || !fdt_in || !dmp || !dmp1 || !fdt_out)) return fail(SPDY_ERR_ARG, "null pointer");
+    const size_t n = nlev * spec_elems(p), tn = (size_t)p->tab.mx * p->tab.nx;
+    RC(h2d(p, p->stage_a, field, n));
+    RC(h2d(p, p->stage_b, fdt_in, n));
+    RC(h2d(p, p->stage_c, dmp, tn));
+    RC(h2d(p, p->stage_d, dmp1, tn));
+    RC(spdy_hdiff_dev(p, nlev, p->stage_a, p->stage_b, p->stage_c, p->stage_d, p->stage_a));
+    RC(d2h(p, fdt_out, p->stage_a, n));
+    return sync(p);
+}
+
+int spdy_implicit_init(spdy_plan *p, double dt)
+{
+    NEED_PLAN(p);
+    const std::string err = p->tab.build_implicit(dt);
+    if (!err.empty()) return fail(SPDY_ERR_UNSUPPORTED, "implicit_init: %s", err.c_str());
+    if (p->device < 0) return SPDY_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const HostTables &t = p->tab;
+    const size_t tn = sizeof(double) * t.mx * t.nx;
+    const std::vector<double> *d1[3] = {&t.dmp1, &t.dmp1d, &t.dmp1s};
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipMemcpy(p->d_dmp[3 + i], d1[i]->data(), tn, hipMemcpyHostToDevice));
+    struct { double *dst; const std::vector<double> *src; } up[6] = {
+        {p->d_xd, &t.xd}, {p->d_xc, &t.xc}, {p->d_xj, &t.xj}, {p->d_tref1, &t.tref1}, {p->d_dhsx, &t.dhsx}, {p->d_elz, &t.elz}};
+    for (auto &u : up) HIP_TRY(hipMemcpy(u.dst, u.src->data(), u.src->size() * sizeof(double), hipMemcpyHostToDevice));
+    return SPDY_OK;
+}
+
+int spdy_implicit_terms_dev(spdy_plan *p, double *divdt, double *tdt, double *psdt)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "implicit_terms before implicit_init");
+    if (!divdt || !tdt || !psdt) return fail(SPDY_ERR_ARG, "null pointer");
+    KERNEL(spdy::launch_implicit(p->dev, divdt, tdt, psdt, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_implicit_terms(spdy_plan *p, double *divdt, double *tdt, double *psdt)
+{
+    NEED_DEVICE(p);
+    if (p->max_batch < p->tab.kx) return fail(SPDY_ERR_ARG, "max_batch must be >= kx for the host implicit_terms");
+    if (!divdt || !tdt || !psdt) return fail(SPDY_ERR_ARG, "null pointer");
+    const size_t n = p->tab.kx * spec_elems(p);
+    RC(h2d(p, p->stage_a, divdt, n));
+    RC(h2d(p, p->stage_b, tdt, n));
+    RC(h2d(p, p->stage_c, psdt, spec_elems(p)));
+    RC(spdy_implicit_terms_dev(p, p->stage_a, p->stage_b, p->stage_c));
+    RC(d2h(p, divdt, p->stage_a, n));
+    RC(d2h(p, tdt, p->stage_b, n));
+    RC(d2h(p, psdt, p->stage_c, spec_elems(p)));
+    return sync(p);
+}
+
+int spdy_device_table(spdy_plan *p, const char *name, const double **d_ptr)
+{
+    NEED_DEVICE(p);
+    if (!name || !d_ptr) return fail(SPDY_ERR_ARG, "null argument");
+    static const char *names[6] = {"dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s"};
+    for (int i = 0; i < 6; ++i)
+        if (!std::strcmp(name, names[i])) {
+            if (i >= 3 && !p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "%s needs implicit_init first", name);
+            *d_ptr = p->d_dmp[i];
+            return SPDY_OK;
+        }
+    return fail(SPDY_ERR_ARG, "no device table '%s'", name);
+}
+
+}  // extern "C"

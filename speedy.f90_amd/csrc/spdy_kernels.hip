@@ -1,0 +1,830 @@
+// gfx950 (MI355X, CDNA4) kernels for the speedy.f90 grid<->spectral path.
+//
+//   legendre_inv / legendre_dir : per-zonal-wavenumber contractions on the FP64 matrix cores
+//                                 (v_mfma_f64_16x16x4_f64); batch (field x re/im) is the N dimension.
+//   fourier_inv / fourier_dir   : FFTPACK-schedule real FFTs (N = 96: 2*4*4*3, N = 192: 4*4*4*3).
+//                                 Each row is split over N/48 lanes; a lane runs a 48-point
+//                                 radix-(4,4,3) sub-transform entirely in registers, the ido=48
+//                                 stage is done through LDS, and LDS is also the transpose
+//                                 buffer that makes every HBM access a full coalesced line.
+//   spectral operators, horizontal diffusion, semi-implicit solve: one lane per coefficient.
+//
+// Numerics: same butterflies, same twiddle values, same float32-derived constants as the
+// reference (tables come from spdy_tables.cpp); only FMA contraction and the order of the
+// Legendre sums differ -> agreement ~1e-15 relative, bar 1e-12.
+#include "spdy_kernels.hpp"
+
+namespace spdy {
+
+#define UNROLL _Pragma("unroll")
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// FFT constants (uniform -> scalar loads).  96 and 192 share the ido=12 / ido=3 stage twiddles
+// mathematically, but each resolution keeps its own copy so plans of both can coexist.
+// ------------------------------------------------------------------------------------------
+__constant__ FftConstants c_fft96;
+__constant__ FftConstants c_fft192;
+
+hipError_t upload_fft_constants(int ix, const FftConstants &c)
+{
+    if (ix == 96) return hipMemcpyToSymbol(HIP_SYMBOL(c_fft96), &c, sizeof(c));
+    if (ix == 192) return hipMemcpyToSymbol(HIP_SYMBOL(c_fft192), &c, sizeof(c));
+    return hipErrorInvalidValue;
+}
+
+template <int NF> __device__ __forceinline__ const FftConstants &fftc();
+template <> __device__ __forceinline__ const FftConstants &fftc<96>() { return c_fft96; }
+template <> __device__ __forceinline__ const FftConstants &fftc<192>() { return c_fft192; }
+
+// ------------------------------------------------------------------------------------------
+// Radix stages on register arrays.  Half-complex (FFTPACK) storage:
+//   backward: in(ido,ip,l1) -> out(ido,l1,ip) ; forward: in(ido,l1,ip) -> out(ido,ip,l1)
+// p = index of a real part (1,3,5..), p+1 its imaginary part, (q,q+1) = (ido-2-p, ido-1-p) the
+// conjugate-mirrored pair.  All indices are compile-time after unrolling -> pure VGPR code.
+// ------------------------------------------------------------------------------------------
+template <int IDO, int L1>
+__device__ __forceinline__ void bwd4(const double (&in)[IDO * 4 * L1], double (&out)[IDO * 4 * L1],
+                                     const double *w, double sqrt2)
+{
+#define I4(i, j, k) in[(i) + IDO * ((j) + 4 * (k))]
+#define O4(i, k, j) out[(i) + IDO * ((k) + L1 * (j))]
+    UNROLL for (int k = 0; k < L1; ++k) {
+        const double tr1 = I4(0, 0, k) - I4(IDO - 1, 3, k), tr2 = I4(0, 0, k) + I4(IDO - 1, 3, k);
+        const double tr3 = I4(IDO - 1, 1, k) + I4(IDO - 1, 1, k), tr4 = I4(0, 2, k) + I4(0, 2, k);
+        O4(0, k, 0) = tr2 + tr3;  O4(0, k, 1) = tr1 - tr4;
+        O4(0, k, 2) = tr2 - tr3;  O4(0, k, 3) = tr1 + tr4;
+        UNROLL for (int p = 1; p + 1 < IDO; p += 2) {
+            const int q = IDO - 2 - p;
+            const double ti1 = I4(p + 1, 0, k) + I4(q + 1, 3, k), ti2 = I4(p + 1, 0, k) - I4(q + 1, 3, k);
+            const double ti3 = I4(p + 1, 2, k) - I4(q + 1, 1, k), tr4b = I4(p + 1, 2, k) + I4(q + 1, 1, k);
+            const double tr1b = I4(p, 0, k) - I4(q, 3, k), tr2b = I4(p, 0, k) + I4(q, 3, k);
+            const double ti4 = I4(p, 2, k) - I4(q, 1, k), tr3b = I4(p, 2, k) + I4(q, 1, k);
+            const double cr3 = tr2b - tr3b, ci3 = ti2 - ti3, cr2 = tr1b - tr4b, cr4 = tr1b + tr4b;
+            const double ci2 = ti1 + ti4, ci4 = ti1 - ti4;
+            O4(p, k, 0) = tr2b + tr3b;
+            O4(p + 1, k, 0) = ti2 + ti3;
+            O4(p, k, 1) = w[p - 1] * cr2 - w[p] * ci2;
+            O4(p + 1, k, 1) = w[p - 1] * ci2 + w[p] * cr2;
+            O4(p, k, 2) = w[IDO + p - 1] * cr3 - w[IDO + p] * ci3;
+            O4(p + 1, k, 2) = w[IDO + p - 1] * ci3 + w[IDO + p] * cr3;
+            O4(p, k, 3) = w[2 * IDO + p - 1] * cr4 - w[2 * IDO + p] * ci4;
+            O4(p + 1, k, 3) = w[2 * IDO + p - 1] * ci4 + w[2 * IDO + p] * cr4;
+        }
+        if (IDO % 2 == 0) {
+            const double ti1 = I4(0, 1, k) + I4(0, 3, k), ti2 = I4(0, 3, k) - I4(0, 1, k);
+            const double ur1 = I4(IDO - 1, 0, k) - I4(IDO - 1, 2, k), ur2 = I4(IDO - 1, 0, k) + I4(IDO - 1, 2, k);
+            O4(IDO - 1, k, 0) = ur2 + ur2;
+            O4(IDO - 1, k, 1) = sqrt2 * (ur1 - ti1);
+            O4(IDO - 1, k, 2) = ti2 + ti2;
+            O4(IDO - 1, k, 3) = -sqrt2 * (ur1 + ti1);
+        }
+    }
+#undef I4
+#undef O4
+}
+
+// radix-3 backward with ido = 1 (the last backward stage): no twiddles
+template <int L1>
+__device__ __forceinline__ void bwd3_ido1(const double (&in)[3 * L1], double (&out)[3 * L1], double taui)
+{
+    UNROLL for (int k = 0; k < L1; ++k) {
+        const double tr2 = in[1 + 3 * k] + in[1 + 3 * k];
+        const double cr2 = in[3 * k] + (-0.5) * tr2;
+        const double ci3 = taui * (in[2 + 3 * k] + in[2 + 3 * k]);
+        out[k] = in[3 * k] + tr2;
+        out[k + L1] = cr2 - ci3;
+        out[k + 2 * L1] = cr2 + ci3;
+    }
+}
+
+// radix-3 forward with ido = 1 (the first forward stage)
+template <int L1>
+__device__ __forceinline__ void fwd3_ido1(const double (&in)[3 * L1], double (&out)[3 * L1], double taui)
+{
+    UNROLL for (int k = 0; k < L1; ++k) {
+        const double cr2 = in[k + L1] + in[k + 2 * L1];
+        out[3 * k] = in[k] + cr2;
+        out[2 + 3 * k] = taui * (in[k + 2 * L1] - in[k + L1]);
+        out[1 + 3 * k] = in[k] + (-0.5) * cr2;
+    }
+}
+
+template <int IDO, int L1>
+__device__ __forceinline__ void fwd4(const double (&in)[IDO * 4 * L1], double (&out)[IDO * 4 * L1],
+                                     const double *w, double hsqt2)
+{
+#define I4(i, k, j) in[(i) + IDO * ((k) + L1 * (j))]
+#define O4(i, j, k) out[(i) + IDO * ((j) + 4 * (k))]
+    UNROLL for (int k = 0; k < L1; ++k) {
+        const double tr1 = I4(0, k, 1) + I4(0, k, 3), tr2 = I4(0, k, 0) + I4(0, k, 2);
+        O4(0, 0, k) = tr1 + tr2;
+        O4(IDO - 1, 3, k) = tr2 - tr1;
+        O4(IDO - 1, 1, k) = I4(0, k, 0) - I4(0, k, 2);
+        O4(0, 2, k) = I4(0, k, 3) - I4(0, k, 1);
+        UNROLL for (int p = 1; p + 1 < IDO; p += 2) {
+            const int q = IDO - 2 - p;
+            const double cr2 = w[p - 1] * I4(p, k, 1) + w[p] * I4(p + 1, k, 1);
+            const double ci2 = w[p - 1] * I4(p + 1, k, 1) - w[p] * I4(p, k, 1);
+            const double cr3 = w[IDO + p - 1] * I4(p, k, 2) + w[IDO + p] * I4(p + 1, k, 2);
+            const double ci3 = w[IDO + p - 1] * I4(p + 1, k, 2) - w[IDO + p] * I4(p, k, 2);
+            const double cr4 = w[2 * IDO + p - 1] * I4(p, k, 3) + w[2 * IDO + p] * I4(p + 1, k, 3);
+            const double ci4 = w[2 * IDO + p - 1] * I4(p + 1, k, 3) - w[2 * IDO + p] * I4(p, k, 3);
+            const double sr1 = cr2 + cr4, sr4 = cr4 - cr2, si1 = ci2 + ci4, si4 = ci2 - ci4;
+            const double si2 = I4(p + 1, k, 0) + ci3, si3 = I4(p + 1, k, 0) - ci3;
+            const double sr2 = I4(p, k, 0) + cr3, sr3 = I4(p, k, 0) - cr3;
+            O4(p, 0, k) = sr1 + sr2;
+            O4(q, 3, k) = sr2 - sr1;
+            O4(p + 1, 0, k) = si1 + si2;
+            O4(q + 1, 3, k) = si1 - si2;
+            O4(p, 2, k) = si4 + sr3;
+            O4(q, 1, k) = sr3 - si4;
+            O4(p + 1, 2, k) = sr4 + si3;
+            O4(q + 1, 1, k) = sr4 - si3;
+        }
+        if (IDO % 2 == 0) {
+            const double ti1 = -hsqt2 * (I4(IDO - 1, k, 1) + I4(IDO - 1, k, 3));
+            const double ur1 = hsqt2 * (I4(IDO - 1, k, 1) - I4(IDO - 1, k, 3));
+            O4(IDO - 1, 0, k) = ur1 + I4(IDO - 1, k, 0);
+            O4(IDO - 1, 2, k) = I4(IDO - 1, k, 0) - ur1;
+            O4(0, 1, k) = ti1 - I4(IDO - 1, k, 2);
+            O4(0, 3, k) = ti1 + I4(IDO - 1, k, 2);
+        }
+    }
+#undef I4
+#undef O4
+}
+
+// 48-point backward sub-transform: radix 4 (ido 12), radix 4 (ido 3), radix 3 (ido 1).
+// Input in x (clobbered), natural-order result in y.
+template <int NF>
+__device__ __forceinline__ void sub48_backward(double (&x)[48], double (&y)[48])
+{
+    const FftConstants &c = fftc<NF>();
+    bwd4<12, 1>(x, y, c.a, c.sqrt2);
+    bwd4<3, 4>(y, x, c.b, c.sqrt2);
+    bwd3_ido1<16>(x, y, c.taui);
+}
+
+// 48-point forward sub-transform: radix 3 (ido 1), radix 4 (ido 3), radix 4 (ido 12).
+template <int NF>
+__device__ __forceinline__ void sub48_forward(double (&x)[48], double (&y)[48])
+{
+    const FftConstants &c = fftc<NF>();
+    fwd3_ido1<16>(x, y, c.taui);
+    fwd4<3, 4>(y, x, c.b, c.hsqt2);
+    fwd4<12, 1>(x, y, c.a, c.hsqt2);
+}
+
+// ------------------------------------------------------------------------------------------
+// fourier_inv  (fourier.f90:23-53 + fftpack rfftb1): four[nb*il][fs] -> grid[nb*il][NF]
+// Block = 64 rows x TPR lanes-per-row; thread = h*64 + r, so h (which 48-point column of the
+// ido=48 stage this lane owns) is wave-uniform.
+// ------------------------------------------------------------------------------------------
+constexpr int FFT_ROWS = 64;
+
+template <int NF, int TWO_MX>
+__global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_inv_kernel(
+    const double *__restrict__ four, double *__restrict__ grid, const double *__restrict__ cosgr,
+    const int *__restrict__ d_kcos, int kcos_all, int nrows, int il, int fs)
+{
+    constexpr int TPR = NF / 48, RS = NF + 1, NT = FFT_ROWS * TPR;
+    constexpr int LASTF = TWO_MX - 2;   // fvar[i] = F[i+1] for 1 <= i <= LASTF, zero beyond
+    __shared__ double tile[FFT_ROWS * RS];
+    const int tid = threadIdx.x, r = tid & (FFT_ROWS - 1), h = tid / FFT_ROWS;
+    const long row0 = (long)blockIdx.x * FFT_ROWS;
+    const int nvalid = (int)min((long)FFT_ROWS, (long)nrows - row0);
+
+    // phase 1: coalesced load of the Fourier rows (first TWO_MX doubles of each fs-stride row)
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(four + row0 * fs);
+        const int per_row = fs / 2;
+        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
+            const int rr = e / per_row, c2 = e - rr * per_row;
+            if (2 * c2 < TWO_MX) {
+                double2 v = make_double2(0.0, 0.0);
+                if (rr < nvalid) v = src[e];
+                tile[rr * RS + 2 * c2] = v.x;
+                tile[rr * RS + 2 * c2 + 1] = v.y;
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2: ido=48 stage (this lane's column h only), then the 48-point sub-transform
+    double x[48], y[48];
+    {
+        const double *rowp = tile + r * RS;
+        const FftConstants &c = fftc<NF>();
+        auto fv = [&](int i) -> double { return i == 0 ? rowp[0] : (i <= LASTF ? rowp[i + 1] : 0.0); };
+        if (TPR == 2) {   // radix 2: in(48,2) -> out(48,1,2)   (fftpack radb2)
+            if (h == 0) {
+                x[0] = fv(0) + fv(95);
+                UNROLL for (int p = 1; p < 47; p += 2) {
+                    const int q = 46 - p;
+                    x[p] = fv(p) + fv(48 + q);
+                    x[p + 1] = fv(p + 1) - fv(48 + q + 1);
+                }
+                x[47] = fv(47) + fv(47);
+            } else {
+                x[0] = fv(0) - fv(95);
+                UNROLL for (int p = 1; p < 47; p += 2) {
+                    const int q = 46 - p;
+                    const double tr2 = fv(p) - fv(48 + q), ti2 = fv(p + 1) + fv(48 + q + 1);
+                    x[p] = c.first[p - 1] * tr2 - c.first[p] * ti2;
+                    x[p + 1] = c.first[p - 1] * ti2 + c.first[p] * tr2;
+                }
+                x[47] = -(fv(48) + fv(48));
+            }
+        } else {          // radix 4: in(48,4) -> out(48,1,4)   (fftpack radb4)
+#define CCF(i, j) fv((i) + 48 * (j))
+            {
+                const double tr1 = CCF(0, 0) - CCF(47, 3), tr2 = CCF(0, 0) + CCF(47, 3);
+                const double tr3 = CCF(47, 1) + CCF(47, 1), tr4 = CCF(0, 2) + CCF(0, 2);
+                x[0] = h == 0 ? tr2 + tr3 : h == 1 ? tr1 - tr4 : h == 2 ? tr2 - tr3 : tr1 + tr4;
+            }
+            UNROLL for (int p = 1; p < 47; p += 2) {
+                const int q = 46 - p;
+                const double ti1 = CCF(p + 1, 0) + CCF(q + 1, 3), ti2 = CCF(p + 1, 0) - CCF(q + 1, 3);
+                const double ti3 = CCF(p + 1, 2) - CCF(q + 1, 1), tr4 = CCF(p + 1, 2) + CCF(q + 1, 1);
+                const double tr1 = CCF(p, 0) - CCF(q, 3), tr2 = CCF(p, 0) + CCF(q, 3);
+                const double ti4 = CCF(p, 2) - CCF(q, 1), tr3 = CCF(p, 2) + CCF(q, 1);
+                if (h == 0) {
+                    x[p] = tr2 + tr3;
+                    x[p + 1] = ti2 + ti3;
+                } else {
+                    const double cr = h == 1 ? tr1 - tr4 : h == 2 ? tr2 - tr3 : tr1 + tr4;
+                    const double ci = h == 1 ? ti1 + ti4 : h == 2 ? ti2 - ti3 : ti1 - ti4;
+                    const double wr = c.first[48 * (h - 1) + p - 1], wi = c.first[48 * (h - 1) + p];
+                    x[p] = wr * cr - wi * ci;
+                    x[p + 1] = wr * ci + wi * cr;
+                }
+            }
+            {
+                const double ti1 = CCF(0, 1) + CCF(0, 3), ti2 = CCF(0, 3) - CCF(0, 1);
+                const double tr1 = CCF(47, 0) - CCF(47, 2), tr2 = CCF(47, 0) + CCF(47, 2);
+                x[47] = h == 0 ? tr2 + tr2 : h == 1 ? c.sqrt2 * (tr1 - ti1) : h == 2 ? ti2 + ti2 : -c.sqrt2 * (tr1 + ti1);
+            }
+#undef CCF
+        }
+    }
+    sub48_backward<NF>(x, y);
+    __syncthreads();
+
+    // phase 3: element t of column h is grid point TPR*t + h
+    {
+        double *rowp = tile + r * RS;
+        UNROLL for (int t = 0; t < 48; ++t) rowp[TPR * t + h] = y[t];
+    }
+    __syncthreads();
+
+    // phase 4: coalesced store (+ optional 1/cos(lat) scaling, fourier.f90:47-51)
+    {
+        double2 *dst = reinterpret_cast<double2 *>(grid + row0 * NF);
+        constexpr int per_row = NF / 2;
+        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
+            const int rr = e / per_row, c2 = e - rr * per_row;
+            if (rr < nvalid) {
+                const long grow = row0 + rr;
+                const int fld = (int)(grow / il), j = (int)(grow - (long)fld * il);
+                const int kc = d_kcos ? d_kcos[fld] : kcos_all;
+                const double sc = kc == 1 ? 1.0 : cosgr[j];
+                double2 v = make_double2(tile[rr * RS + 2 * c2], tile[rr * RS + 2 * c2 + 1]);
+                if (kc != 1) { v.x *= sc; v.y *= sc; }
+                dst[e] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fourier_dir  (fourier.f90:56-82 + fftpack rfftf1): grid[nb*il][NF] -> four[nb*il][fs]
+// ------------------------------------------------------------------------------------------
+template <int NF, int TWO_MX>
+__global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_dir_kernel(
+    const double *__restrict__ grid, const double *__restrict__ gscale, double *__restrict__ four,
+    int nrows, int il, int fs)
+{
+    constexpr int TPR = NF / 48, RS = NF + 1, NT = FFT_ROWS * TPR;
+    __shared__ double tile[FFT_ROWS * RS];
+    const int tid = threadIdx.x, r = tid & (FFT_ROWS - 1), h = tid / FFT_ROWS;
+    const long row0 = (long)blockIdx.x * FFT_ROWS;
+    const int nvalid = (int)min((long)FFT_ROWS, (long)nrows - row0);
+    const FftConstants &c = fftc<NF>();
+
+    // phase 1: coalesced load of 64 grid rows (optionally scaled per latitude: vdspec)
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(grid + row0 * NF);
+        constexpr int per_row = NF / 2;
+        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
+            const int rr = e / per_row, c2 = e - rr * per_row;
+            double2 v = make_double2(0.0, 0.0);
+            if (rr < nvalid) {
+                v = src[e];
+                if (gscale) {
+                    const double sc = gscale[(int)((row0 + rr) % il)];
+                    v.x *= sc; v.y *= sc;
+                }
+            }
+            tile[rr * RS + 2 * c2] = v.x;
+            tile[rr * RS + 2 * c2 + 1] = v.y;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: decimated samples TPR*t + h -> 48-point forward sub-transform
+    double x[48], y[48];
+    {
+        const double *rowp = tile + r * RS;
+        UNROLL for (int t = 0; t < 48; ++t) x[t] = rowp[TPR * t + h];
+    }
+    sub48_forward<NF>(x, y);
+    __syncthreads();
+    {
+        double *rowp = tile + r * RS + 48 * h;
+        UNROLL for (int i = 0; i < 48; ++i) rowp[i] = y[i];
+    }
+    __syncthreads();
+
+    // phase 3: the ido=48 stage, in place.  Butterflies p and 46-p touch the same 4*TPR slots,
+    // so one lane does both: 13 work items per row (item 0 = the i=0 and i=47 specials).
+    {
+        double *z = tile + r * RS;
+        for (int it = h; it < 13; it += TPR) {
+            if (TPR == 2) {        // fftpack radf2, ido=48, l1=1: in(48,1,2) -> out(48,2,1)
+                if (it == 0) {
+                    const double a0 = z[0], a1 = z[48], b0 = z[47], b1 = z[95];
+                    z[0] = a0 + a1;  z[95] = a0 - a1;  z[48] = -b1;  z[47] = b0;
+                } else {
+                    const int p = 2 * it - 1, q = 46 - p;
+                    const double wr = c.first[p - 1], wi = c.first[p];
+                    const double a0r = z[p], a0i = z[p + 1], a1r = z[48 + p], a1i = z[48 + p + 1];
+                    const double tr2 = wr * a1r + wi * a1i, ti2 = wr * a1i - wi * a1r;
+                    if (p == q) {
+                        z[p + 1] = a0i + ti2;  z[48 + q + 1] = ti2 - a0i;
+                        z[p] = a0r + tr2;      z[48 + q] = a0r - tr2;
+                    } else {
+                        const double vr = c.first[q - 1], vi = c.first[q];
+                        const double b0r = z[q], b0i = z[q + 1], b1r = z[48 + q], b1i = z[48 + q + 1];
+                        const double sr2 = vr * b1r + vi * b1i, si2 = vr * b1i - vi * b1r;
+                        z[p + 1] = a0i + ti2;  z[48 + q + 1] = ti2 - a0i;
+                        z[p] = a0r + tr2;      z[48 + q] = a0r - tr2;
+                        z[q + 1] = b0i + si2;  z[48 + p + 1] = si2 - b0i;
+                        z[q] = b0r + sr2;      z[48 + p] = b0r - sr2;
+                    }
+                }
+            } else {               // fftpack radf4, ido=48, l1=1: in(48,1,4) -> out(48,4,1)
+                if (it == 0) {
+                    const double a0 = z[0], a1 = z[48], a2 = z[96], a3 = z[144];
+                    const double e0 = z[47], e1 = z[95], e2 = z[143], e3 = z[191];
+                    const double tr1 = a1 + a3, tr2 = a0 + a2;
+                    const double ti1 = -c.hsqt2 * (e1 + e3), ur1 = c.hsqt2 * (e1 - e3);
+                    z[0] = tr1 + tr2;        z[144 + 47] = tr2 - tr1;
+                    z[48 + 47] = a0 - a2;    z[96] = a3 - a1;
+                    z[47] = ur1 + e0;        z[96 + 47] = e0 - ur1;
+                    z[48] = ti1 - e2;        z[144] = ti1 + e2;
+                } else {
+                    const int p = 2 * it - 1, q = 46 - p;
+                    double in[2][8];
+                    UNROLL for (int s = 0; s < 2; ++s) {
+                        const int pp = s == 0 ? p : q;
+                        UNROLL for (int j = 0; j < 4; ++j) { in[s][2 * j] = z[48 * j + pp]; in[s][2 * j + 1] = z[48 * j + pp + 1]; }
+                    }
+                    UNROLL for (int s = 0; s < 2; ++s) {
+                        if (s == 1 && p == q) break;
+                        const int pp = s == 0 ? p : q, qq = s == 0 ? q : p;
+                        const double *a = in[s];
+                        const double cr2 = c.first[pp - 1] * a[2] + c.first[pp] * a[3];
+                        const double ci2 = c.first[pp - 1] * a[3] - c.first[pp] * a[2];
+                        const double cr3 = c.first[48 + pp - 1] * a[4] + c.first[48 + pp] * a[5];
+                        const double ci3 = c.first[48 + pp - 1] * a[5] - c.first[48 + pp] * a[4];
+                        const double cr4 = c.first[96 + pp - 1] * a[6] + c.first[96 + pp] * a[7];
+                        const double ci4 = c.first[96 + pp - 1] * a[7] - c.first[96 + pp] * a[6];
+                        const double sr1 = cr2 + cr4, sr4 = cr4 - cr2, si1 = ci2 + ci4, si4 = ci2 - ci4;
+                        const double si2 = a[1] + ci3, si3 = a[1] - ci3, sr2 = a[0] + cr3, sr3 = a[0] - cr3;
+                        z[pp] = sr1 + sr2;            z[144 + qq] = sr2 - sr1;
+                        z[pp + 1] = si1 + si2;        z[144 + qq + 1] = si1 - si2;
+                        z[96 + pp] = si4 + sr3;       z[48 + qq] = sr3 - si4;
+                        z[96 + pp + 1] = sr4 + si3;   z[48 + qq + 1] = sr4 - si3;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 4: scale by float32(1/N), pack (a0, 0, re1, im1, ...) and store coalesced
+    {
+        double2 *dst = reinterpret_cast<double2 *>(four + row0 * fs);
+        const int per_row = fs / 2;
+        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
+            const int rr = e / per_row, c2 = e - rr * per_row;
+            if (rr < nvalid) {
+                double2 v = make_double2(0.0, 0.0);
+                const double *z = tile + rr * RS;
+                if (c2 == 0) v.x = z[0] * c.scale;
+                else if (2 * c2 < TWO_MX) { v.x = z[2 * c2 - 1] * c.scale; v.y = z[2 * c2] * c.scale; }
+                dst[e] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// legendre_inv (legendre.f90:74-111) on the FP64 matrix cores.
+// Block = (8 fields) x (8 zonal wavenumbers); wave w owns m' = 8*blockIdx.y + w.
+//   D[j, c] = sum_n A[j, n] * B[n, c],  A = P(m', n, j) (16-latitude tile), B = X(n, c),
+//   c = 2*field + (re|im); one accumulator pair (even-n, odd-n parity) per latitude tile.
+// North/south rows: out(il-1-j) = even + odd, out(j) = even - odd.
+// ------------------------------------------------------------------------------------------
+constexpr int LEG_BT = 8;      // fields per block
+constexpr int LEG_MG = 8;      // zonal wavenumbers per block (one 128-byte line of spec)
+constexpr int LEG_NT = 64 * LEG_MG;
+
+template <int JT>
+__global__ __launch_bounds__(LEG_NT) void legendre_inv_kernel(DevPlan p, int nb, const double *__restrict__ spec,
+                                                               double *__restrict__ four)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // [w][parity][kp][16] (+2 pad per w)
+    const int kp = 4 * p.ks_inv, wstride = 2 * kp * 16 + 2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = blockIdx.x * LEG_BT, m0 = blockIdx.y * LEG_MG;
+
+    for (int e = tid; e < LEG_MG * wstride; e += LEG_NT) xs[e] = 0.0;
+    __syncthreads();
+    // stage X: one (re,im) pair per lane, 8 consecutive m' = one 128-byte line
+    {
+        const int total = LEG_BT * p.nx * LEG_MG;
+        for (int e = tid; e < total; e += LEG_NT) {
+            const int mi = e & (LEG_MG - 1), t = e >> 3, n = t % p.nx, b = t / p.nx;
+            const int m = m0 + mi;
+            if (b0 + b < nb && m < p.mx && m + n <= p.trunc + 1) {
+                const double2 v = *reinterpret_cast<const double2 *>(spec + 2 * (((long)(b0 + b) * p.nx + n) * p.mx + m));
+                double *d = xs + mi * wstride + ((n & 1) * kp + (n >> 1)) * 16 + 2 * b;
+                d[0] = v.x;
+                d[1] = v.y;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int m = m0 + w;
+    if (m >= p.mx) return;
+    const int kact = p.nx - m;                       // active n: 0 .. kact-1
+    d4 acc[2][JT];
+    UNROLL for (int q = 0; q < 2; ++q) {
+        UNROLL for (int t = 0; t < JT; ++t) acc[q][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    UNROLL for (int par = 0; par < 2; ++par) {
+        const int cnt = (kact + 1 - par) >> 1, nks = (cnt + 3) >> 2;
+        const double *bsrc = xs + w * wstride + par * kp * 16 + (lane >> 4) * 16 + (lane & 15);
+        const double *asrc = p.pa_inv + ((long)(m * 2 + par) * p.ks_inv) * JT * 64 + lane;
+        for (int ks = 0; ks < nks; ++ks) {
+            const double bv = bsrc[ks * 64];
+            UNROLL for (int t = 0; t < JT; ++t) {
+                const double av = asrc[(ks * JT + t) * 64];
+                acc[par][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[par][t], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: row = (lane>>4) + 4*reg, col = lane&15
+    const int col = lane & 15, fld = b0 + (col >> 1), part = col & 1;
+    if (fld < nb) {
+        double *base = four + (long)fld * p.il * p.fs + 2 * m + part;
+        UNROLL for (int t = 0; t < JT; ++t) {
+            UNROLL for (int rg = 0; rg < 4; ++rg) {
+                const int j = 16 * t + (lane >> 4) + 4 * rg;
+                if (j < p.iy) {
+                    const double ev = acc[0][t][rg], od = acc[1][t][rg];
+                    base[(long)(p.il - 1 - j) * p.fs] = ev + od;
+                    base[(long)j * p.fs] = ev - od;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// legendre_dir (legendre.f90:114-155) on the FP64 matrix cores.
+//   D[n, c] = sum_j A[n, j] * B[j, c],  A = P(m', n, j)*wt(j) (16-row n tile of one parity),
+//   B = F(il-1-j, c) +/- F(j, c) (+ for n even 0-based, - for n odd).
+// ------------------------------------------------------------------------------------------
+template <int NTD>
+__global__ __launch_bounds__(LEG_NT) void legendre_dir_kernel(DevPlan p, int nb, const double *__restrict__ four,
+                                                               double *__restrict__ spec)
+{
+    extern __shared__ __attribute__((aligned(16))) double fsm[];   // [w][il][16] (+2 pad per w)
+    const int wstride = p.il * 16 + 2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = blockIdx.x * LEG_BT, m0 = blockIdx.y * LEG_MG;
+    {
+        const int total = LEG_BT * p.il * LEG_MG;
+        for (int e = tid; e < total; e += LEG_NT) {
+            const int mi = e & (LEG_MG - 1), t = e >> 3, row = t % p.il, b = t / p.il;
+            double2 v = make_double2(0.0, 0.0);
+            if (b0 + b < nb && m0 + mi < p.mx)
+                v = *reinterpret_cast<const double2 *>(four + ((long)(b0 + b) * p.il + row) * p.fs + 2 * (m0 + mi));
+            double *d = fsm + mi * wstride + row * 16 + 2 * b;
+            d[0] = v.x;
+            d[1] = v.y;
+        }
+    }
+    __syncthreads();
+
+    const int m = m0 + w;
+    if (m >= p.mx) return;
+    // active n (0-based): n <= trunc and m + n <= trunc + 1
+    const int nact = min(p.trunc + 1, p.trunc + 2 - m);
+    int ntile[2];
+    UNROLL for (int par = 0; par < 2; ++par) ntile[par] = (((nact + 1 - par) >> 1) + 15) >> 4;
+    d4 acc[2][NTD];
+    UNROLL for (int q = 0; q < 2; ++q) {
+        UNROLL for (int t = 0; t < NTD; ++t) acc[q][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    const double *fw = fsm + w * wstride + (lane & 15);
+    for (int ks = 0; ks < p.js_dir; ++ks) {
+        const int j = 4 * ks + (lane >> 4);
+        const double south = fw[(p.il - 1 - j) * 16], north = fw[j * 16];
+        const double bv[2] = {south + north, south - north};
+        UNROLL for (int par = 0; par < 2; ++par) {
+            const double *asrc = p.pa_dir + (((long)(m * 2 + par) * p.nt_dir) * p.js_dir + ks) * 64 + lane;
+            UNROLL for (int t = 0; t < NTD; ++t) {
+                if (t < ntile[par])
+                    acc[par][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(asrc[(long)t * p.js_dir * 64], bv[par],
+                                                                       acc[par][t], 0, 0, 0);
+            }
+        }
+    }
+    const int col = lane & 15, fld = b0 + (col >> 1), part = col & 1;
+    if (fld < nb) {
+        double *base = spec + 2 * ((long)fld * p.nx * p.mx + m) + part;
+        UNROLL for (int par = 0; par < 2; ++par) {
+            UNROLL for (int t = 0; t < NTD; ++t) {
+                UNROLL for (int rg = 0; rg < 4; ++rg) {
+                    const int n = 2 * (16 * t + (lane >> 4) + 4 * rg) + par;
+                    if (n < p.nx) base[2 * (long)n * p.mx] = acc[par][t][rg];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Spectral-space operators: one lane per complex coefficient (b, n, m).
+// ------------------------------------------------------------------------------------------
+struct cpx { double re, im; };
+__device__ __forceinline__ cpx ld(const double *a, long i) { const double2 v = *reinterpret_cast<const double2 *>(a + 2 * i); return {v.x, v.y}; }
+__device__ __forceinline__ void st(double *a, long i, cpx z) { *reinterpret_cast<double2 *>(a + 2 * i) = make_double2(z.re, z.im); }
+__device__ __forceinline__ cpx operator*(double r, cpx z) { return {r * z.re, r * z.im}; }
+__device__ __forceinline__ cpx operator+(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cpx operator-(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cpx operator-(cpx a) { return {-a.re, -a.im}; }
+__device__ __forceinline__ cpx times_i(cpx a) { return {a.re * 0.0 - a.im, a.re + a.im * 0.0}; }   // * (0,1)
+
+// laplacian / inverse_laplacian / trunct (spectral.f90:84-96, 229-233)
+__global__ void scale_op_kernel(DevPlan p, int op, long total, const double *__restrict__ in, double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i % (p.mx * p.nx));
+    const cpx z = ld(in, i);
+    if (op == OP_LAPLACIAN) st(out, i, p.el2[e] * (-z));
+    else if (op == OP_INV_LAPLACIAN) st(out, i, p.elm2[e] * (-z));
+    else st(out, i, p.trfilt[e] * z);
+}
+
+// grad (spectral.f90:124-144)
+__global__ void grad_kernel(DevPlan p, long total, const double *__restrict__ psi, double *__restrict__ dx, double *__restrict__ dy)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int sz = p.mx * p.nx, e = (int)(i % sz), m = e % p.mx, n = e / p.mx;
+    const long f0 = i - e;
+    st(dx, i, times_i(p.gradx[m] * ld(psi, i)));
+    cpx r;
+    if (n == 0) r = p.gradyp[e] * ld(psi, f0 + m + p.mx);
+    else if (n == p.nx - 1) r = (-p.gradym[e]) * ld(psi, f0 + m + (long)p.mx * p.trunc);
+    else if (n <= p.trunc) r = (-p.gradym[e]) * ld(psi, i - p.mx) + p.gradyp[e] * ld(psi, i + p.mx);
+    else return;
+    st(dy, i, r);
+}
+
+// vds (spectral.f90:146-171): (U,V) -> (vor,div)
+__global__ void vds_kernel(DevPlan p, long total, const double *__restrict__ u, const double *__restrict__ v,
+                           double *__restrict__ vor, double *__restrict__ dv)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int sz = p.mx * p.nx, e = (int)(i % sz), m = e % p.mx, n = e / p.mx;
+    const long f0 = i - e;
+    if (n == 0) {
+        const cpx zp = times_i(p.gradx[m] * ld(u, i)), zc = times_i(p.gradx[m] * ld(v, i));
+        st(vor, i, zc - p.vddyp[e] * ld(u, i + p.mx));
+        st(dv, i, zp + p.vddyp[e] * ld(v, i + p.mx));
+    } else if (n == p.nx - 1) {
+        const long k = f0 + m + (long)p.mx * p.trunc;
+        st(vor, i, p.vddym[e] * ld(u, k));
+        st(dv, i, (-p.vddym[e]) * ld(v, k));
+    } else if (n <= p.trunc) {
+        const cpx zp = times_i(p.gradx[m] * ld(u, i)), zc = times_i(p.gradx[m] * ld(v, i));
+        st(vor, i, (p.vddym[e] * ld(u, i - p.mx) - p.vddyp[e] * ld(u, i + p.mx)) + zc);
+        st(dv, i, ((-p.vddym[e]) * ld(v, i - p.mx) + p.vddyp[e] * ld(v, i + p.mx)) + zp);
+    }
+}
+
+// uvspec (spectral.f90:173-196): (vor,div) -> (U,V)
+__global__ void uvspec_kernel(DevPlan p, long total, const double *__restrict__ vor, const double *__restrict__ dv,
+                              double *__restrict__ u, double *__restrict__ v)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int sz = p.mx * p.nx, e = (int)(i % sz), m = e % p.mx, n = e / p.mx;
+    const long f0 = i - e;
+    if (n == 0) {
+        const cpx zp = times_i(p.uvdx[e] * ld(vor, i)), zc = times_i(p.uvdx[e] * ld(dv, i));
+        st(u, i, zc - p.uvdyp[e] * ld(vor, i + p.mx));
+        st(v, i, zp + p.uvdyp[e] * ld(dv, i + p.mx));
+    } else if (n == p.nx - 1) {
+        const long k = f0 + m + (long)p.mx * p.trunc;
+        st(u, i, p.uvdym[e] * ld(vor, k));
+        st(v, i, (-p.uvdym[e]) * ld(dv, k));
+    } else if (n <= p.trunc) {
+        const cpx zp = times_i(p.uvdx[e] * ld(vor, i)), zc = times_i(p.uvdx[e] * ld(dv, i));
+        st(v, i, ((-p.uvdym[e]) * ld(dv, i - p.mx) + p.uvdyp[e] * ld(dv, i + p.mx)) + zp);
+        st(u, i, (p.uvdym[e] * ld(vor, i - p.mx) - p.uvdyp[e] * ld(vor, i + p.mx)) + zc);
+    }
+}
+
+// do_horizontal_diffusion (horizontal_diffusion.f90:86-105)
+__global__ void hdiff_kernel(int sz, long total, const double *__restrict__ field, const double *__restrict__ fdt,
+                             const double *__restrict__ dmp, const double *__restrict__ dmp1, double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i % sz);
+    st(out, i, dmp1[e] * (ld(fdt, i) - dmp[e] * ld(field, i)));
+}
+
+// implicit_terms (implicit.f90:168-217): one lane per (m,n); the kx x kx mat-vecs run in
+// registers in the reference's summation order.
+constexpr int MAXK = 8;
+__global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *__restrict__ tdt, double *__restrict__ psdt)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, sz = p.mx * p.nx, kx = p.kx;
+    if (e >= sz) return;
+    const int m = e % p.mx, n = e / p.mx, l = m + n;
+    cpx t[MAXK], ye[MAXK], yf[MAXK], d[MAXK];
+    cpx ps = ld(psdt, e);
+    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) { t[k] = ld(tdt, (long)k * sz + e); ye[k] = {0.0, 0.0}; }
+    UNROLL for (int k1 = 0; k1 < MAXK; ++k1) {
+        if (k1 < kx) {
+            UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) ye[k] = ye[k] + p.xd[k + kx * k1] * t[k1];
+        }
+    }
+    const double ez = p.elz[e];
+    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) {
+        ye[k] = ye[k] + p.tref1[k] * ps;
+        yf[k] = ld(divdt, (long)k * sz + e) + ez * ye[k];
+        d[k] = {0.0, 0.0};
+    }
+    if (l != 0) {
+        const double *xj = p.xj + (long)kx * kx * (l - 1);
+        UNROLL for (int k1 = 0; k1 < MAXK; ++k1) {
+            if (k1 < kx) {
+                UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) d[k] = d[k] + xj[k + kx * k1] * yf[k1];
+            }
+        }
+    }
+    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) ps = ps - p.dhsx[k] * d[k];
+    UNROLL for (int k = 0; k < MAXK; ++k) {
+        if (k < kx) {
+            UNROLL for (int k1 = 0; k1 < MAXK; ++k1) if (k1 < kx) t[k] = t[k] + p.xc[k + kx * k1] * d[k1];
+        }
+    }
+    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) { st(divdt, (long)k * sz + e, d[k]); st(tdt, (long)k * sz + e, t[k]); }
+    st(psdt, e, ps);
+}
+
+// ------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------
+hipError_t launch_legendre_inv(const DevPlan &p, int nb, const double *spec, double *four, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    const dim3 grid((nb + LEG_BT - 1) / LEG_BT, (p.mx + LEG_MG - 1) / LEG_MG);
+    const size_t lds = sizeof(double) * LEG_MG * (2 * 4 * p.ks_inv * 16 + 2);
+    if (p.jt == 2) hipLaunchKernelGGL(legendre_inv_kernel<2>, grid, dim3(LEG_NT), lds, s, p, nb, spec, four);
+    else if (p.jt == 3) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(legendre_inv_kernel<3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(legendre_inv_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, spec, four);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_legendre_dir(const DevPlan &p, int nb, const double *four, double *spec, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    const dim3 grid((nb + LEG_BT - 1) / LEG_BT, (p.mx + LEG_MG - 1) / LEG_MG);
+    const size_t lds = sizeof(double) * LEG_MG * (p.il * 16 + 2);
+    if (p.nt_dir == 1) hipLaunchKernelGGL(legendre_dir_kernel<1>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
+    else if (p.nt_dir == 3) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(legendre_dir_kernel<3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(legendre_dir_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, const int *d_kcos, int kcos_all,
+                              double *grid, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    const int nrows = nb * p.il, nblk = (nrows + FFT_ROWS - 1) / FFT_ROWS;
+    if (p.ix == 96 && p.mx == 31)
+        hipLaunchKernelGGL((fourier_inv_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, four, grid, p.cosgr,
+                           d_kcos, kcos_all, nrows, p.il, p.fs);
+    else if (p.ix == 192 && p.mx == 64)
+        hipLaunchKernelGGL((fourier_inv_kernel<192, 128>), dim3(nblk), dim3(FFT_ROWS * 4), 0, s, four, grid, p.cosgr,
+                           d_kcos, kcos_all, nrows, p.il, p.fs);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, const double *gscale, double *four,
+                              hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    const int nrows = nb * p.il, nblk = (nrows + FFT_ROWS - 1) / FFT_ROWS;
+    if (p.ix == 96 && p.mx == 31)
+        hipLaunchKernelGGL((fourier_dir_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, grid, gscale, four,
+                           nrows, p.il, p.fs);
+    else if (p.ix == 192 && p.mx == 64)
+        hipLaunchKernelGGL((fourier_dir_kernel<192, 128>), dim3(nblk), dim3(FFT_ROWS * 4), 0, s, grid, gscale, four,
+                           nrows, p.il, p.fs);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+static inline dim3 blocks_for(long total) { return dim3((unsigned)((total + 255) / 256)); }
+
+hipError_t launch_scale_op(const DevPlan &p, int op, int nb, const double *in, double *out, hipStream_t s)
+{
+    const long total = (long)nb * p.mx * p.nx;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_op_kernel, blocks_for(total), dim3(256), 0, s, p, op, total, in, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad(const DevPlan &p, int nb, const double *psi, double *psdx, double *psdy, hipStream_t s)
+{
+    const long total = (long)nb * p.mx * p.nx;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(grad_kernel, blocks_for(total), dim3(256), 0, s, p, total, psi, psdx, psdy);
+    return hipGetLastError();
+}
+
+hipError_t launch_vds(const DevPlan &p, int nb, const double *u, const double *v, double *vor, double *div, hipStream_t s)
+{
+    const long total = (long)nb * p.mx * p.nx;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(vds_kernel, blocks_for(total), dim3(256), 0, s, p, total, u, v, vor, div);
+    return hipGetLastError();
+}
+
+hipError_t launch_uvspec(const DevPlan &p, int nb, const double *vor, const double *div, double *u, double *v, hipStream_t s)
+{
+    const long total = (long)nb * p.mx * p.nx;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(uvspec_kernel, blocks_for(total), dim3(256), 0, s, p, total, vor, div, u, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const double *fdt, const double *dmp,
+                        const double *dmp1, double *out, hipStream_t s)
+{
+    const long total = (long)nlev * p.mx * p.nx;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hdiff_kernel, blocks_for(total), dim3(256), 0, s, p.mx * p.nx, total, field, fdt, dmp, dmp1, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s)
+{
+    if (p.kx > MAXK) return hipErrorInvalidValue;
+    const int sz = p.mx * p.nx;
+    hipLaunchKernelGGL(implicit_kernel, dim3((sz + 63) / 64), dim3(64), 0, s, p, divdt, tdt, psdt);
+    return hipGetLastError();
+}
+
+}  // namespace spdy

@@ -1,0 +1,52 @@
+// Launch interface between the C-ABI layer (spdy_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace spdy {
+
+// Device-side view of a plan: dimensions + table pointers (all device memory).
+struct DevPlan {
+    int trunc, ix, iy, il, kx, nx, mx;
+    int fs;        // row stride (doubles) of the Fourier workspace: 2*mx rounded up to 16
+    int ks_inv;    // k-steps (of 4 n's) per parity in the inverse-Legendre A table
+    int jt;        // 16-latitude tiles per hemisphere (ceil(iy/16))
+    int nt_dir;    // 16-row n tiles per parity in the direct-Legendre A table
+    int js_dir;    // k-steps (of 4 latitudes) in the direct transform (iy/4)
+    const double *pa_inv;   // [mx][2][ks_inv][jt][64]      P(m,n,j)            MFMA A fragments
+    const double *pa_dir;   // [mx][2][nt_dir][js_dir][64]  P(m,n,j)*wt(j)      MFMA A fragments
+    const double *cosgr;    // [il]
+    const double *cosgr2;   // [il]
+    // spectral operator tables, each [nx][mx] (gradx: [mx])
+    const double *el2, *elm2, *trfilt, *gradx, *gradym, *gradyp, *uvdx, *uvdym, *uvdyp, *vddym, *vddyp;
+    // implicit tables
+    const double *xd, *xc, *xj, *tref1, *dhsx, *elz;
+};
+
+// FFTPACK twiddles / constants for one resolution; copied to __constant__ memory once.
+struct FftConstants {
+    double first[144];  // stage with ido=48: 1 block (N=96, radix 2) or 3 blocks (N=192, radix 4)
+    double a[36];       // radix-4 stage, ido=12: 3 blocks of 12
+    double b[9];        // radix-4 stage, ido=3 : 3 blocks of 3
+    double taui, sqrt2, hsqt2, scale;
+};
+hipError_t upload_fft_constants(int ix, const FftConstants &c);
+
+// four: [nb][il][fs] workspace layout.  All launches are asynchronous on `s`.
+hipError_t launch_legendre_inv(const DevPlan &p, int nb, const double *spec, double *four, hipStream_t s);
+hipError_t launch_legendre_dir(const DevPlan &p, int nb, const double *four, double *spec, hipStream_t s);
+hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, const int *d_kcos, int kcos_all,
+                              double *grid, hipStream_t s);
+// gscale: nullptr, or a per-latitude factor applied to the grid on load (vdspec's cosgr/cosgr2)
+hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, const double *gscale, double *four,
+                              hipStream_t s);
+
+enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };
+hipError_t launch_scale_op(const DevPlan &p, int op, int nb, const double *in, double *out, hipStream_t s);
+hipError_t launch_grad(const DevPlan &p, int nb, const double *psi, double *psdx, double *psdy, hipStream_t s);
+hipError_t launch_vds(const DevPlan &p, int nb, const double *u, const double *v, double *vor, double *div, hipStream_t s);
+hipError_t launch_uvspec(const DevPlan &p, int nb, const double *vor, const double *div, double *u, double *v, hipStream_t s);
+hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const double *fdt, const double *dmp,
+                        const double *dmp1, double *out, hipStream_t s);
+hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s);
+
+}  // namespace spdy

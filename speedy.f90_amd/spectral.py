@@ -1,0 +1,228 @@
+"""Python mirror of the reference's `spectral` module (spectral.f90:8-11) over the C-ABI.
+
+Same public names, argument meaning and result shapes as the Fortran module, plus batched
+and device-resident variants.  Arrays are NumPy C-order views of the reference's column-major
+arrays (axes reversed):
+
+    grid  vorg(ix,il)          -> float64    [..., il, ix]
+    spec  vorm(mx,nx) complex  -> complex128 [..., nx, mx]
+    four  (2*mx,il)            -> float64    [..., il, 2*mx]
+
+Leading dimensions are the batch (e.g. the kx levels of a (mx,nx,kx) array).  Host methods
+accept/return NumPy arrays; *_dev methods take torch CUDA tensors (device memory stays where
+it is, kernels run on torch's current stream).
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import check, load
+
+RESOLUTIONS = {"t30": (30, 96, 24), "t63": (63, 192, 48)}   # trunc, ix, iy
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Spectral:
+    """One transform plan = the module state `initialize_spectral` builds (spectral.f90:20)."""
+
+    def __init__(self, res="t30", kx=8, max_batch=64, device=0):
+        trunc, ix, iy = RESOLUTIONS[res] if isinstance(res, str) else res
+        self.lib = load()
+        h = ctypes.c_void_p()
+        check(self.lib.spdy_plan_create(trunc, ix, iy, kx, max_batch, device, ctypes.byref(h)))
+        self.h = h
+        self.trunc, self.ix, self.iy, self.il, self.kx = trunc, ix, iy, 2 * iy, kx
+        self.nx, self.mx, self.max_batch, self.device = trunc + 2, trunc + 1, max_batch, device
+        self.grid_shape, self.spec_shape = (self.il, self.ix), (self.nx, self.mx)
+        self.four_shape = (self.il, 2 * self.mx)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.spdy_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ------------------------------------------------------------------ helpers
+    def _in(self, a, shape, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if a.shape[-len(shape):] != tuple(shape):
+            raise ValueError("expected trailing shape %s, got %s" % (shape, a.shape))
+        lead = a.shape[:-len(shape)]
+        nb = int(np.prod(lead)) if lead else 1
+        return a, lead, nb
+
+    def table(self, name):
+        n = check(self.lib.spdy_get_table(self.h, name.encode(), None, 0))
+        out = np.zeros(n)
+        check(self.lib.spdy_get_table(self.h, name.encode(), _p(out), n))
+        return out
+
+    @property
+    def el2(self):
+        """Public table of the reference module (spectral.f90:8)."""
+        return self.table("el2").reshape(self.spec_shape)
+
+    # ------------------------------------------------------------------ transforms (host arrays)
+    def spec_to_grid(self, vorm, kcos=1):
+        """spectral.f90:98 -- kcos: int or per-field sequence."""
+        s, lead, nb = self._in(vorm, self.spec_shape, np.complex128)
+        g = np.empty(lead + self.grid_shape)
+        kc = np.ascontiguousarray(np.broadcast_to(np.asarray(kcos, np.int32), (nb,)))
+        check(self.lib.spdy_spec_to_grid_batch(self.h, nb, _p(s), _p(kc), _p(g)))
+        return g
+
+    def grid_to_spec(self, vorg):
+        """spectral.f90:112"""
+        g, lead, nb = self._in(vorg, self.grid_shape, np.float64)
+        s = np.empty(lead + self.spec_shape, np.complex128)
+        check(self.lib.spdy_grid_to_spec_batch(self.h, nb, _p(g), _p(s)))
+        return s
+
+    def legendre_inv(self, s):
+        s, lead, nb = self._in(s, self.spec_shape, np.complex128)
+        f = np.empty(lead + self.four_shape)
+        check(self.lib.spdy_legendre_inv(self.h, nb, _p(s), _p(f)))
+        return f
+
+    def legendre_dir(self, f):
+        f, lead, nb = self._in(f, self.four_shape, np.float64)
+        s = np.empty(lead + self.spec_shape, np.complex128)
+        check(self.lib.spdy_legendre_dir(self.h, nb, _p(f), _p(s)))
+        return s
+
+    def fourier_inv(self, f, kcos=1):
+        f, lead, nb = self._in(f, self.four_shape, np.float64)
+        g = np.empty(lead + self.grid_shape)
+        check(self.lib.spdy_fourier_inv(self.h, nb, _p(f), int(kcos), _p(g)))
+        return g
+
+    def fourier_dir(self, g):
+        g, lead, nb = self._in(g, self.grid_shape, np.float64)
+        f = np.empty(lead + self.four_shape)
+        check(self.lib.spdy_fourier_dir(self.h, nb, _p(g), _p(f)))
+        return f
+
+    # ------------------------------------------------------------------ spectral operators
+    def laplacian(self, a):
+        a, lead, nb = self._in(a, self.spec_shape, np.complex128)
+        o = np.empty_like(a)
+        check(self.lib.spdy_laplacian(self.h, nb, _p(a), _p(o)))
+        return o
+
+    def inverse_laplacian(self, a):
+        a, lead, nb = self._in(a, self.spec_shape, np.complex128)
+        o = np.empty_like(a)
+        check(self.lib.spdy_inverse_laplacian(self.h, nb, _p(a), _p(o)))
+        return o
+
+    def trunct(self, a):
+        a, lead, nb = self._in(a, self.spec_shape, np.complex128)
+        a = a.copy()
+        check(self.lib.spdy_trunct(self.h, nb, _p(a)))
+        return a
+
+    def grad(self, psi):
+        psi, lead, nb = self._in(psi, self.spec_shape, np.complex128)
+        dx, dy = np.zeros_like(psi), np.zeros_like(psi)
+        check(self.lib.spdy_grad(self.h, nb, _p(psi), _p(dx), _p(dy)))
+        return dx, dy
+
+    def vds(self, ucosm, vcosm):
+        u, lead, nb = self._in(ucosm, self.spec_shape, np.complex128)
+        v, _, _ = self._in(vcosm, self.spec_shape, np.complex128)
+        vor, div = np.zeros_like(u), np.zeros_like(u)
+        check(self.lib.spdy_vds(self.h, nb, _p(u), _p(v), _p(vor), _p(div)))
+        return vor, div
+
+    def uvspec(self, vorm, divm):
+        a, lead, nb = self._in(vorm, self.spec_shape, np.complex128)
+        b, _, _ = self._in(divm, self.spec_shape, np.complex128)
+        u, v = np.zeros_like(a), np.zeros_like(a)
+        check(self.lib.spdy_uvspec(self.h, nb, _p(a), _p(b), _p(u), _p(v)))
+        return u, v
+
+    def vdspec(self, ug, vg, kcos=2):
+        ug, lead, nb = self._in(ug, self.grid_shape, np.float64)
+        vg, _, _ = self._in(vg, self.grid_shape, np.float64)
+        vor = np.zeros(lead + self.spec_shape, np.complex128)
+        div = np.zeros_like(vor)
+        check(self.lib.spdy_vdspec(self.h, nb, _p(ug), _p(vg), _p(vor), _p(div), int(kcos)))
+        return vor, div
+
+    # ------------------------------------------------------------------ spectral-space tail
+    def do_horizontal_diffusion(self, field, fdt_in, dmp, dmp1):
+        """horizontal_diffusion.f90:86-105 (2-D or 3-D by the leading dimension)."""
+        field, lead, nlev = self._in(field, self.spec_shape, np.complex128)
+        fdt_in, _, _ = self._in(fdt_in, self.spec_shape, np.complex128)
+        dmp = np.ascontiguousarray(dmp, np.float64)
+        dmp1 = np.ascontiguousarray(dmp1, np.float64)
+        out = np.empty_like(field)
+        check(self.lib.spdy_hdiff(self.h, nlev, _p(field), _p(fdt_in), _p(dmp), _p(dmp1), _p(out)))
+        return out
+
+    def initialize_implicit(self, dt):
+        """implicit.f90:36"""
+        check(self.lib.spdy_implicit_init(self.h, float(dt)))
+
+    def implicit_terms(self, divdt, tdt, psdt):
+        """implicit.f90:168 (returns the updated copies)."""
+        d = np.array(divdt, np.complex128, order="C")
+        t = np.array(tdt, np.complex128, order="C")
+        p = np.array(psdt, np.complex128, order="C")
+        if d.shape != (self.kx,) + self.spec_shape or t.shape != d.shape or p.shape != self.spec_shape:
+            raise ValueError("implicit_terms expects (kx,nx,mx),(kx,nx,mx),(nx,mx)")
+        check(self.lib.spdy_implicit_terms(self.h, _p(d), _p(t), _p(p)))
+        return d, t, p
+
+    # ------------------------------------------------------------------ device-resident batch (torch tensors)
+    def use_torch_stream(self):
+        import torch
+        check(self.lib.spdy_plan_set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    KERNEL_KINDS = ("legendre_inv", "fourier_inv", "fourier_dir", "legendre_dir")
+
+    def set_profiling(self, on=True):
+        check(self.lib.spdy_plan_set_profiling(self.h, 1 if on else 0))
+
+    def get_profile(self):
+        """{kernel kind: (total ms, launches)} measured with HIP events on the launch stream."""
+        ms = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_int * 4)()
+        check(self.lib.spdy_plan_get_profile(self.h, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNEL_KINDS)}
+
+    def synchronize(self):
+        check(self.lib.spdy_plan_synchronize(self.h))
+
+    @staticmethod
+    def _dp(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def spec_to_grid_dev(self, d_spec, d_grid, kcos=1, d_kcos=None):
+        """d_spec: [nb, nx, mx] complex128 (or [nb,nx,mx,2] float64) CUDA tensor; d_grid: [nb, il, ix] float64."""
+        nb = d_grid.shape[0]
+        check(self.lib.spdy_spec_to_grid_dev(self.h, nb, self._dp(d_spec), self._dp(d_kcos) if d_kcos is not None else None,
+                                             int(kcos), self._dp(d_grid)))
+
+    def grid_to_spec_dev(self, d_grid, d_spec):
+        nb = d_grid.shape[0]
+        check(self.lib.spdy_grid_to_spec_dev(self.h, nb, self._dp(d_grid), self._dp(d_spec)))
+
+    def uvspec_dev(self, vor, div, u, v):
+        check(self.lib.spdy_uvspec_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(u), self._dp(v)))
+
+    def vdspec_dev(self, ug, vg, vor, div, kcos=2):
+        check(self.lib.spdy_vdspec_dev(self.h, ug.shape[0], self._dp(ug), self._dp(vg), self._dp(vor), self._dp(div), int(kcos)))
+
+    def implicit_terms_dev(self, divdt, tdt, psdt):
+        check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
+
+    def hdiff_dev(self, field, fdt_in, dmp_name, dmp1_name, out):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(self.lib.spdy_device_table(self.h, dmp_name.encode(), ctypes.byref(a)))
+        check(self.lib.spdy_device_table(self.h, dmp1_name.encode(), ctypes.byref(b)))
+        check(self.lib.spdy_hdiff_dev(self.h, field.shape[0], self._dp(field), self._dp(fdt_in), a, b, self._dp(out)))

@@ -1,0 +1,220 @@
+"""GPU: parity of the HIP path (through the C-ABI) against the reference.
+
+Bar (north_star / SURVEY.md s8c):  max|x - x_ref| / max|x_ref| <= 1e-12  per output array, FP64.
+The checker is the golden vectors (reference outputs) and the C oracle (pinned to them by
+tests/test_oracle_golden.py); nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+import synth
+from conftest import TOL
+from golden.make_golden import tail_inputs
+
+pytestmark = pytest.mark.gpu
+TAGS = ("t30", "t63")
+
+
+@pytest.fixture(scope="module")
+def plans():
+    import speedy_f90_amd as s
+    cache = {}
+
+    def get(tag, max_batch=256):
+        key = (tag, max_batch)
+        if key not in cache:
+            cache[key] = s.Spectral(tag, kx=8, max_batch=max_batch, device=0)
+        return cache[key]
+    yield get
+    for p in cache.values():
+        p.close()
+
+
+def ok(x, ref, tol=TOL):
+    assert x.shape == ref.shape
+    err = synth.relerr(x, ref)
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_stages_vs_golden(tag, plans, golden):
+    g, sp = golden(tag), plans(tag)
+    nb = g["leginv"].shape[0]
+    S, G = g["S"][:nb], g["G"][:nb]
+    ok(sp.legendre_inv(S), g["leginv"])
+    ok(sp.fourier_inv(g["leginv"], 1), g["finv1"])
+    ok(sp.fourier_inv(g["leginv"], 2), g["finv2"])
+    ok(sp.fourier_dir(G), g["fdir"])
+    ok(sp.legendre_dir(g["fdir"]), g["legdir"])
+    ok(sp.spec_to_grid(S, 1), g["s2g1"])
+    ok(sp.spec_to_grid(S, 2), g["s2g2"])
+    ok(sp.grid_to_spec(G), g["g2s"])
+    # single-field drop-in signatures
+    ok(sp.spec_to_grid(S[0], 2), g["s2g2"][0])
+    ok(sp.grid_to_spec(G[0]), g["g2s"][0])
+    s1 = sp.grid_to_spec(np.ones(sp.grid_shape))
+    ok(s1, g["ones_g2s"])
+    # structural facts of the reference: row nx and everything outside the triangle is exactly 0
+    out = sp.grid_to_spec(G)
+    assert np.all(out[:, -1, :] == 0)
+    l = np.add.outer(np.arange(sp.nx), np.arange(sp.mx))
+    assert np.all(out[:, l > sp.trunc + 1] == 0)
+    assert np.all(sp.fourier_dir(G)[:, :, 1] == 0)      # Im(m'=0) written as 0 (fourier.f90:76)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_operators_vs_golden(tag, plans, golden):
+    g, sp = golden(tag), plans(tag)
+    S, G = g["S"], g["G"]
+    ok(sp.laplacian(S[0]), g["lap"])
+    ok(sp.inverse_laplacian(S[0]), g["invlap"])
+    ok(sp.trunct(S[0]), g["trunct"])
+    dx, dy = sp.grad(S[0]); ok(dx, g["grad_dx"]); ok(dy, g["grad_dy"])
+    a, b = sp.vds(S[0], S[1]); ok(a, g["vds_vor"]); ok(b, g["vds_div"])
+    a, b = sp.uvspec(S[0], S[1]); ok(a, g["uv_u"]); ok(b, g["uv_v"])
+    a, b = sp.vdspec(G[0], G[1], 2); ok(a, g["vdspec2_vor"]); ok(b, g["vdspec2_div"])
+    a, b = sp.vdspec(G[0], G[1], 1); ok(a, g["vdspec1_vor"]); ok(b, g["vdspec1_div"])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_tail_vs_golden(tag, plans, golden):
+    g, sp = golden(tag), plans(tag)
+    div, t, ps = tail_inputs(sp.kx, sp.nx, sp.mx)
+    for dt in g["dts"]:
+        key = "dt%d_" % int(dt)
+        sp.initialize_implicit(float(dt))
+        if dt in g["imp_dts"]:
+            a, b, c = sp.implicit_terms(div, t, ps)
+            ok(a, g[key + "imp_div_out"]); ok(b, g[key + "imp_t_out"]); ok(c, g[key + "imp_ps_out"])
+        if key + "hdiff2d" in g.files:
+            ok(sp.do_horizontal_diffusion(ps, 2 * ps, g[key + "dmps"], g[key + "dmp1s"]), g[key + "hdiff2d"])
+        if key + "hdiff3d" in g.files:
+            ok(sp.do_horizontal_diffusion(t, div, g[key + "dmp"], g[key + "dmp1"]), g[key + "hdiff3d"])
+
+
+@pytest.mark.parametrize("tag,nb", [("t30", 1), ("t30", 7), ("t30", 48), ("t30", 73), ("t30", 91), ("t30", 129),
+                                    ("t63", 1), ("t63", 9), ("t63", 96)])
+def test_batches_vs_oracle(tag, nb, plans, oracle_factory):
+    """Model-shaped batches (48 / 73 / 91) and ragged ones, mixed kcos."""
+    sp, o = plans(tag), oracle_factory(tag)
+    S = synth.spectra(nb, sp.trunc, first=1000, full_rows=True)
+    G = synth.grids(nb, sp.ix, sp.il, first=1000)
+    kcos = np.array([2 if (b % 6) in (4, 5) else 1 for b in range(nb)], np.int32)   # u,v slots of every 6
+    got = sp.spec_to_grid(S, kcos)
+    ref = np.stack([o.spec_to_grid(S[b], int(kcos[b])) for b in range(nb)])
+    for b in range(nb):
+        ok(got[b], ref[b])
+    got = sp.grid_to_spec(G)
+    ref = np.stack([o.grid_to_spec(G[b]) for b in range(nb)])
+    for b in range(nb):
+        ok(got[b], ref[b])
+
+
+def test_empty_batch(plans):
+    sp = plans("t30")
+    assert sp.grid_to_spec(np.zeros((0,) + sp.grid_shape)).shape == (0,) + sp.spec_shape
+    assert sp.spec_to_grid(np.zeros((0,) + sp.spec_shape, np.complex128)).shape == (0,) + sp.grid_shape
+
+
+def test_inactive_coefficients_are_ignored(plans, oracle_factory):
+    """The inverse transform must not read l > trunc+1 (legendre.f90:93: m <= nsh2(n))."""
+    sp, o = plans("t30"), oracle_factory("t30")
+    S = synth.spectra(2, 30, first=5, full_rows=True)
+    junk = S.copy()
+    l = np.add.outer(np.arange(sp.nx), np.arange(sp.mx))
+    junk[:, l > sp.trunc + 1] = 1e300 + 1e300j
+    ok(sp.spec_to_grid(junk, 1), np.stack([o.spec_to_grid(S[b], 1) for b in range(2)]))
+    # Im(m'=0) is dropped by fourier_inv (fourier.f90:34-36)
+    junk = S.copy(); junk[:, :, 0] += 3.0j
+    ok(sp.spec_to_grid(junk, 1), np.stack([o.spec_to_grid(S[b], 1) for b in range(2)]))
+
+
+def test_max_batch_enforced(plans):
+    import speedy_f90_amd as s
+    sp = plans("t30", 256)
+    with pytest.raises(s.SpdyError):
+        sp.grid_to_spec(np.zeros((257,) + sp.grid_shape))
+
+
+@pytest.mark.parametrize("tag,nb", [("t30", 6144), ("t63", 1536)])
+def test_full_size_device_resident(tag, nb, oracle_factory):
+    """BASELINE sizes (B=6144 at T30, 1536 at T63; ~226 MB of grid data), device-resident path on
+    torch's stream.  Checked against the oracle on a strided sample of fields plus two
+    size-independent properties over the whole batch: linearity and batch independence."""
+    import torch
+    import speedy_f90_amd as s
+    o = oracle_factory(tag)
+    sp = s.Spectral(tag, kx=8, max_batch=nb, device=0)
+    sp.use_torch_stream()
+    uniq = 64
+    G = synth.grids(uniq, sp.ix, sp.il, first=7000)
+    reps = nb // uniq
+    dG = torch.from_numpy(G).cuda().repeat(reps, 1, 1).contiguous()
+    scale = torch.arange(1, nb + 1, dtype=torch.float64, device="cuda").view(nb, 1, 1) / nb
+    dG = dG * scale                                   # every field distinct
+    dS = torch.zeros((nb, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+    dG2 = torch.zeros_like(dG)
+    sp.grid_to_spec_dev(dG, dS)
+    sp.spec_to_grid_dev(dS, dG2, kcos=1)
+    torch.cuda.synchronize()
+    hS, hG2, hG = dS.cpu().numpy(), dG2.cpu().numpy(), dG.cpu().numpy()
+    for b in list(range(0, nb, 97)) + [nb - 1]:
+        ok(hS[b], o.grid_to_spec(hG[b]))
+        ok(hG2[b], o.spec_to_grid(hS[b], 1))
+    # batch independence + linearity: field b is (b+1)/nb times its template field
+    base = hS[:uniq] / (np.arange(1, uniq + 1).reshape(-1, 1, 1) / nb)
+    rel = np.abs(hS / (np.arange(1, nb + 1).reshape(-1, 1, 1) / nb) - np.tile(base, (reps, 1, 1)))
+    assert rel.max() <= 1e-12 * np.abs(base).max()
+    # T(a*x + y) = a*T(x) + T(y)
+    a = 0.37
+    dMix = a * dG[:uniq] + dG[uniq:2 * uniq]
+    dSm = torch.zeros((uniq, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+    sp.grid_to_spec_dev(dMix.contiguous(), dSm)
+    torch.cuda.synchronize()
+    lin = (a * dS[:uniq] + dS[uniq:2 * uniq] - dSm).abs().max().item()
+    assert lin <= 1e-12 * dS[:2 * uniq].abs().max().item()
+    sp.close()
+
+
+def test_device_ops_and_profile(oracle_factory):
+    """Device-pointer operator entry points + the HIP-event profiler used by bench.py."""
+    import torch
+    import speedy_f90_amd as s
+    o = oracle_factory("t30")
+    sp = s.Spectral("t30", kx=8, max_batch=64, device=0)
+    sp.use_torch_stream()
+    S = synth.spectra(16, 30, first=300, full_rows=True)
+    G = synth.grids(16, sp.ix, sp.il, first=300)
+    dS = torch.from_numpy(S).cuda()
+    u, v = torch.zeros_like(dS[:8]), torch.zeros_like(dS[:8])
+    sp.uvspec_dev(dS[:8].contiguous(), dS[8:].contiguous(), u, v)
+    dG = torch.from_numpy(G).cuda()
+    vor, div = torch.zeros_like(dS[:8]), torch.zeros_like(dS[:8])
+    sp.vdspec_dev(dG[:8].contiguous(), dG[8:].contiguous(), vor, div, 2)
+    torch.cuda.synchronize()
+    for b in range(8):
+        ru, rv = o.uvspec(S[b], S[8 + b])
+        ok(u[b].cpu().numpy(), ru); ok(v[b].cpu().numpy(), rv)
+        rvor, rdiv = o.vdspec(G[b], G[8 + b], 2)
+        ok(vor[b].cpu().numpy(), rvor); ok(div[b].cpu().numpy(), rdiv)
+    # implicit + hdiff on device
+    sp.initialize_implicit(4800.0); o.tail_init(4800.0)
+    d, t, p = tail_inputs(8, sp.nx, sp.mx)
+    dd, dt_, dp = torch.from_numpy(d).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(p).cuda()
+    out = torch.zeros_like(dt_)
+    sp.hdiff_dev(dt_, dd, "dmp", "dmp1", out)
+    sp.implicit_terms_dev(dd, dt_, dp)
+    torch.cuda.synchronize()
+    ok(out.cpu().numpy(), o.hdiff(t, d, o.table("dmp"), o.table("dmp1")))
+    ra, rb, rc = o.implicit_terms(d, t, p)
+    ok(dd.cpu().numpy(), ra); ok(dt_.cpu().numpy(), rb); ok(dp.cpu().numpy(), rc)
+    # profiler
+    sp.set_profiling(True)
+    g2 = torch.zeros_like(dG)
+    s2 = torch.zeros_like(dS)
+    for _ in range(3):
+        sp.grid_to_spec_dev(dG, s2); sp.spec_to_grid_dev(s2, g2)
+    prof = sp.get_profile()
+    assert all(prof[k][1] == 3 and prof[k][0] > 0 for k in sp.KERNEL_KINDS)
+    sp.set_profiling(False)
+    sp.close()

@@ -1,0 +1,127 @@
+"""CPU: host logic of the product -- C-ABI surface, table generation, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import ROOT
+
+TAGS = ("t30", "t63")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import speedy_f90_amd as s
+    if not os.path.exists(s.LIB_PATH):
+        s.build()
+    return s
+
+
+def test_cabi_exports_every_declared_symbol(pkg):
+    """include/spdy.h is the contract: every function it declares must be exported and bound."""
+    hdr = open(os.path.join(ROOT, "include", "spdy.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(spdy_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export " + name
+    from importlib import import_module
+    sigs = import_module("speedy_f90_amd._lib").SIGNATURES
+    assert declared - {"spdy_last_error"} == set(sigs), "python binding and header disagree"
+    # nothing leaks except the C ABI
+    out = os.popen("nm -D --defined-only %s" % pkg.LIB_PATH).read()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert {e for e in exported if e.startswith("spdy_")} == declared
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_product_tables_match_oracle(tag, pkg, oracle_factory):
+    """Product table generation (csrc/spdy_tables.cpp) is an independent implementation of the
+    reference recipes; it must agree with the oracle bit for bit (both are plain IEEE)."""
+    sp = pkg.Spectral(tag, device=-1)
+    o = oracle_factory(tag)
+    names = ["sia_half", "cosgr", "cosgr2", "hsg", "dhs", "fsg", "dhsr", "fsgr", "work", "ifac", "epsi", "wt",
+             "poly", "nsh2", "el2", "elm2", "el4", "trfilt", "gradx", "gradyp", "uvdx", "uvdym", "uvdyp",
+             "vddym", "vddyp", "dmp", "dmpd", "dmps"]
+    for n in names:
+        assert np.array_equal(sp.table(n), o.table(n)), n
+    assert np.array_equal(sp.table("gradym").reshape(o.nx, o.mx)[1:], o.table("gradym").reshape(o.nx, o.mx)[1:])
+    assert np.array_equal(sp.table("coa_half")[: o.iy], o.table("coa_half")[: o.iy])
+    for dt in (1200.0, 4800.0):
+        sp.initialize_implicit(dt)
+        o.tail_init(dt)
+        for n in ("dmp1", "dmp1d", "dmp1s", "tref", "tref1", "tref2", "tref3", "xc", "xd", "xj", "dhsx", "elz"):
+            assert np.array_equal(sp.table(n), o.table(n)), (dt, n)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_product_tables_match_golden(tag, pkg, golden):
+    sp = pkg.Spectral(tag, device=-1)
+    g = golden(tag)
+    for n in ("sia_half", "cosgr", "cosgr2", "hsg", "dhs", "fsg", "dhsr", "fsgr", "work"):
+        assert np.array_equal(sp.table(n), g["tab_" + n]), n
+    assert np.array_equal(sp.table("epsi"), g["tab_epsi"].ravel())
+    assert np.array_equal(sp.table("el2"), g["tab_el2"].ravel())
+    sp.initialize_implicit(4800.0)
+    for n in ("dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s", "tref", "tref2", "tref3"):
+        assert np.array_equal(sp.table(n), g["dt4800_" + n].ravel()), n
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a device every compute entry point fails loudly (SPDY_ERR_NO_DEVICE)."""
+    sp = pkg.Spectral("t30", device=-1)
+    with pytest.raises(pkg.SpdyError) as e:
+        sp.grid_to_spec(np.zeros(sp.grid_shape))
+    assert e.value.code == -3
+    with pytest.raises(pkg.SpdyError):
+        sp.spec_to_grid(np.zeros(sp.spec_shape, np.complex128))
+    with pytest.raises(pkg.SpdyError):
+        sp.uvspec(np.zeros(sp.spec_shape, np.complex128), np.zeros(sp.spec_shape, np.complex128))
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        with pytest.raises(pkg.SpdyError) as e:
+            pkg.Spectral("t30", device=0)
+        assert e.value.code == -3
+
+
+def test_argument_errors(pkg):
+    with pytest.raises(pkg.SpdyError) as e:
+        pkg.Spectral((21, 64, 16), device=-1)
+    assert e.value.code == -2                       # unsupported resolution
+    with pytest.raises(pkg.SpdyError):
+        pkg.Spectral("t30", max_batch=0, device=-1)
+    sp = pkg.Spectral("t30", kx=6, device=-1)
+    with pytest.raises(pkg.SpdyError):              # no sigma levels for kx=6 (geometry.f90:42-48)
+        sp.initialize_implicit(2400.0)
+    with pytest.raises(pkg.SpdyError):
+        sp.table("no_such_table")
+    with pytest.raises(ValueError):
+        sp.grid_to_spec(np.zeros((3, 3)))
+
+
+def test_product_does_not_touch_oracle():
+    """The product tree must not reference oracle/ in any form."""
+    pk = os.path.join(ROOT, "speedy.f90_amd")
+    for dirpath, _, files in os.walk(pk):
+        if os.path.basename(dirpath) in ("build", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".f90", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in txt.lower().replace("oracle/ in any form", ""), os.path.join(dirpath, f)
+
+
+def test_synth_reproducible():
+    a = synth.splitmix64(20240229, 4)
+    assert np.allclose(a, synth.splitmix64(20240229, 4))
+    s = synth.spectra(2, 30)
+    assert s.shape == (2, 32, 31) and np.all(s[:, :, 0].imag == 0) and np.all(s[:, 31, :] == 0)
+    assert np.all(s[0][np.add.outer(np.arange(32), np.arange(31)) > 30] == 0)
