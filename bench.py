@@ -39,6 +39,7 @@ def algorithmic_bytes(sp):
     four = 2 * sp.mx * sp.il * 8
     return {"legendre_inv": spec + four, "fourier_inv": four + grid,
             "fourier_dir": grid + four, "legendre_dir": four + spec,
+            "s2g_fused": spec + grid, "g2s_fused": grid + spec,
             "round_trip": 2 * (spec + grid)}
 
 
@@ -71,6 +72,7 @@ def main():
     ap.add_argument("--res", default="t30", choices=["t30", "t63"])
     ap.add_argument("--batch", type=int, default=0, help="fields per GPU (default 6144 at T30, 1536 at T63)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=-1, help="1 fused single-pass kernels, 0 four-kernel path, -1 auto")
     args = ap.parse_args()
 
     import torch
@@ -93,6 +95,7 @@ def main():
     nb = args.batch or (6144 if args.res == "t30" else 1536)
     sp = s.Spectral(args.res, kx=8, max_batch=nb, device=local)
     sp.use_torch_stream()
+    sp.set_fused(args.fused)
 
     # synthetic white-noise grids: 64 seeded templates tiled and rescaled per field so
     # that every field of the batch is distinct; each rank owns its own shard of the batch index

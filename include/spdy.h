@@ -61,8 +61,11 @@ int spdy_plan_synchronize(spdy_plan *plan);
  * synchronises, adds up milliseconds and launch counts per kernel kind (arrays of
  * SPDY_K_COUNT) and clears the record.                                                       */
 enum { SPDY_K_LEGENDRE_INV = 0, SPDY_K_FOURIER_INV = 1, SPDY_K_FOURIER_DIR = 2, SPDY_K_LEGENDRE_DIR = 3,
-       SPDY_K_COUNT = 4 };
+       SPDY_K_S2G_FUSED = 4, SPDY_K_G2S_FUSED = 5, SPDY_K_COUNT = 6 };
 int spdy_plan_set_profiling(spdy_plan *plan, int on);
+/* Kernel selection for the transforms: 1 = fused single-pass kernels (T30; default when the batch is
+ * large enough to fill the chip), 0 = the four-kernel path (any resolution), -1 = automatic.    */
+int spdy_plan_set_fused(spdy_plan *plan, int mode);
 int spdy_plan_get_profile(spdy_plan *plan, double *ms, int *launches);
 /* dims[0..7] = trunc, ix, iy, il, kx, nx, mx, max_batch */
 int spdy_plan_dims(const spdy_plan *plan, int *dims);

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +31,8 @@ struct spdy_plan {
     // device copies of dt-dependent tables
     double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
+    int num_cu = 256;
+    int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
     struct Span { int kind; hipEvent_t t0, t1; };
@@ -229,6 +232,14 @@ int sync(spdy_plan *p)
 
 // Launch one transform kernel; when profiling is on, bracket it with HIP events recorded on
 // the very stream it runs on (kind: SPDY_K_*).
+// Fused single-pass kernels exist for T30; they need enough tiles (4 fields each) to occupy the CUs.
+bool use_fused(const spdy_plan *p, int nb)
+{
+    if (p->tab.trunc != 30 || p->fused_mode == 0) return false;
+    if (p->fused_mode == 1) return true;
+    return nb >= 2 * p->num_cu;      // >= half a tile per CU; below that the 4-kernel path spreads better
+}
+
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
     if (!p->profiling) { HIP_TRY(launch()); return SPDY_OK; }
@@ -277,6 +288,12 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
         if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&p->own_stream)) != hipSuccess)
             rc = fail(SPDY_ERR_HIP, "device init: %s", hipGetErrorString(e));
         p->stream = p->own_stream;
+        if (!rc) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                p->num_cu = prop.multiProcessorCount;
+            if (const char *env = getenv("SPDY_FUSED")) p->fused_mode = atoi(env);
+        }
         if (!rc) rc = upload_all(p);
         if (rc) {
             const std::string keep = g_err;
@@ -319,6 +336,14 @@ int spdy_plan_set_profiling(spdy_plan *p, int on)
 {
     NEED_DEVICE(p);
     p->profiling = on != 0;
+    return SPDY_OK;
+}
+
+int spdy_plan_set_fused(spdy_plan *p, int mode)
+{
+    NEED_PLAN(p);
+    if (mode < -1 || mode > 1) return fail(SPDY_ERR_ARG, "fused mode must be -1, 0 or 1");
+    p->fused_mode = mode;
     return SPDY_OK;
 }
 
@@ -368,6 +393,10 @@ int spdy_spec_to_grid_dev(spdy_plan *p, int nb, const double *d_spec, const int 
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
+    if (use_fused(p, nb))
+        return timed(p, SPDY_K_S2G_FUSED, [&] {
+            return spdy::launch_s2g_fused(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu, p->stream);
+        });
     RC(timed(p, SPDY_K_LEGENDRE_INV, [&] { return spdy::launch_legendre_inv(p->dev, nb, d_spec, p->four, p->stream); }));
     RC(timed(p, SPDY_K_FOURIER_INV, [&] { return spdy::launch_fourier_inv(p->dev, nb, p->four, d_kcos, kcos_all, d_grid, p->stream); }));
     return SPDY_OK;
@@ -378,6 +407,10 @@ int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
+    if (use_fused(p, nb))
+        return timed(p, SPDY_K_G2S_FUSED, [&] {
+            return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu, p->stream);
+        });
     RC(timed(p, SPDY_K_FOURIER_DIR, [&] { return spdy::launch_fourier_dir(p->dev, nb, d_grid, nullptr, p->four, p->stream); }));
     RC(timed(p, SPDY_K_LEGENDRE_DIR, [&] { return spdy::launch_legendre_dir(p->dev, nb, p->four, d_spec, p->stream); }));
     return SPDY_OK;
@@ -508,6 +541,12 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
+    if (use_fused(p, nb)) {
+        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, p->stage_c, p->num_cu, p->stream));
+        KERNEL(spdy::launch_g2s_fused(p->dev, nb, vg, sc, p->stage_d, p->num_cu, p->stream));
+        KERNEL(spdy::launch_vds(p->dev, nb, p->stage_c, p->stage_d, vorm, divm, p->stream));
+        return SPDY_OK;
+    }
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, ug, sc, p->four, p->stream));
     KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_c, p->stream));
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, vg, sc, p->four, p->stream));

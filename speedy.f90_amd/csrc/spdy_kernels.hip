@@ -157,6 +157,19 @@ __device__ __forceinline__ void fwd4(const double (&in)[IDO * 4 * L1], double (&
 
 // 48-point backward sub-transform: radix 4 (ido 12), radix 4 (ido 3), radix 3 (ido 1).
 // Input in x (clobbered), natural-order result in y.
+__device__ __forceinline__ void sub48_backward_c(const FftConstants &c, double (&x)[48], double (&y)[48])
+{
+    bwd4<12, 1>(x, y, c.a, c.sqrt2);
+    bwd4<3, 4>(y, x, c.b, c.sqrt2);
+    bwd3_ido1<16>(x, y, c.taui);
+}
+__device__ __forceinline__ void sub48_forward_c(const FftConstants &c, double (&x)[48], double (&y)[48])
+{
+    fwd3_ido1<16>(x, y, c.taui);
+    fwd4<3, 4>(y, x, c.b, c.hsqt2);
+    fwd4<12, 1>(x, y, c.a, c.hsqt2);
+}
+
 template <int NF>
 __device__ __forceinline__ void sub48_backward(double (&x)[48], double (&y)[48])
 {
@@ -704,6 +717,8 @@ __global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *_
     UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) { st(divdt, (long)k * sz + e, d[k]); st(tdt, (long)k * sz + e, t[k]); }
     st(psdt, e, ps);
 }
+
+#include "spdy_fused_t30.inc"
 
 // ------------------------------------------------------------------------------------------
 // Launchers

@@ -183,15 +183,19 @@ class Spectral:
         import torch
         check(self.lib.spdy_plan_set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    KERNEL_KINDS = ("legendre_inv", "fourier_inv", "fourier_dir", "legendre_dir")
+    KERNEL_KINDS = ("legendre_inv", "fourier_inv", "fourier_dir", "legendre_dir", "s2g_fused", "g2s_fused")
+
+    def set_fused(self, mode):
+        """1 = fused single-pass kernels (T30), 0 = four-kernel path, -1 = automatic by batch size."""
+        check(self.lib.spdy_plan_set_fused(self.h, int(mode)))
 
     def set_profiling(self, on=True):
         check(self.lib.spdy_plan_set_profiling(self.h, 1 if on else 0))
 
     def get_profile(self):
         """{kernel kind: (total ms, launches)} measured with HIP events on the launch stream."""
-        ms = (ctypes.c_double * 4)()
-        cnt = (ctypes.c_int * 4)()
+        ms = (ctypes.c_double * 6)()
+        cnt = (ctypes.c_int * 6)()
         check(self.lib.spdy_plan_get_profile(self.h, ms, cnt))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNEL_KINDS)}
 

@@ -20,10 +20,11 @@ def plans():
     import speedy_f90_amd as s
     cache = {}
 
-    def get(tag, max_batch=256):
+    def get(tag, max_batch=256, fused=-1):
         key = (tag, max_batch)
         if key not in cache:
             cache[key] = s.Spectral(tag, kx=8, max_batch=max_batch, device=0)
+        cache[key].set_fused(fused)      # 1 = fused single-pass kernels (T30), 0 = four-kernel path
         return cache[key]
     yield get
     for p in cache.values():
@@ -36,9 +37,9 @@ def ok(x, ref, tol=TOL):
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("tag", TAGS)
-def test_stages_vs_golden(tag, plans, golden):
-    g, sp = golden(tag), plans(tag)
+@pytest.mark.parametrize("tag,fused", [("t30", 0), ("t30", 1), ("t63", 0)])
+def test_stages_vs_golden(tag, fused, plans, golden):
+    g, sp = golden(tag), plans(tag, fused=fused)
     nb = g["leginv"].shape[0]
     S, G = g["S"][:nb], g["G"][:nb]
     ok(sp.legendre_inv(S), g["leginv"])
@@ -62,9 +63,9 @@ def test_stages_vs_golden(tag, plans, golden):
     assert np.all(sp.fourier_dir(G)[:, :, 1] == 0)      # Im(m'=0) written as 0 (fourier.f90:76)
 
 
-@pytest.mark.parametrize("tag", TAGS)
-def test_operators_vs_golden(tag, plans, golden):
-    g, sp = golden(tag), plans(tag)
+@pytest.mark.parametrize("tag,fused", [("t30", 0), ("t30", 1), ("t63", 0)])
+def test_operators_vs_golden(tag, fused, plans, golden):
+    g, sp = golden(tag), plans(tag, fused=fused)
     S, G = g["S"], g["G"]
     ok(sp.laplacian(S[0]), g["lap"])
     ok(sp.inverse_laplacian(S[0]), g["invlap"])
@@ -92,11 +93,14 @@ def test_tail_vs_golden(tag, plans, golden):
             ok(sp.do_horizontal_diffusion(t, div, g[key + "dmp"], g[key + "dmp1"]), g[key + "hdiff3d"])
 
 
-@pytest.mark.parametrize("tag,nb", [("t30", 1), ("t30", 7), ("t30", 48), ("t30", 73), ("t30", 91), ("t30", 129),
-                                    ("t63", 1), ("t63", 9), ("t63", 96)])
-def test_batches_vs_oracle(tag, nb, plans, oracle_factory):
-    """Model-shaped batches (48 / 73 / 91) and ragged ones, mixed kcos."""
-    sp, o = plans(tag), oracle_factory(tag)
+@pytest.mark.parametrize("tag,nb,fused", [("t30", 1, 0), ("t30", 7, 0), ("t30", 48, 0), ("t30", 73, 0), ("t30", 91, 0),
+                                          ("t30", 129, 0), ("t30", 1, 1), ("t30", 2, 1), ("t30", 5, 1), ("t30", 48, 1),
+                                          ("t30", 73, 1), ("t30", 91, 1), ("t30", 129, 1), ("t30", 255, 1),
+                                          ("t63", 1, 0), ("t63", 9, 0), ("t63", 96, 0)])
+def test_batches_vs_oracle(tag, nb, fused, plans, oracle_factory):
+    """Model-shaped batches (48 / 73 / 91) and ragged ones (partial 4-field tiles of the
+    fused kernels), mixed kcos, through both kernel paths."""
+    sp, o = plans(tag, fused=fused), oracle_factory(tag)
     S = synth.spectra(nb, sp.trunc, first=1000, full_rows=True)
     G = synth.grids(nb, sp.ix, sp.il, first=1000)
     kcos = np.array([2 if (b % 6) in (4, 5) else 1 for b in range(nb)], np.int32)   # u,v slots of every 6
@@ -118,15 +122,20 @@ def test_empty_batch(plans):
 
 def test_inactive_coefficients_are_ignored(plans, oracle_factory):
     """The inverse transform must not read l > trunc+1 (legendre.f90:93: m <= nsh2(n))."""
-    sp, o = plans("t30"), oracle_factory("t30")
+    sp, o = plans("t30", fused=1), oracle_factory("t30")
     S = synth.spectra(2, 30, first=5, full_rows=True)
     junk = S.copy()
     l = np.add.outer(np.arange(sp.nx), np.arange(sp.mx))
     junk[:, l > sp.trunc + 1] = 1e300 + 1e300j
-    ok(sp.spec_to_grid(junk, 1), np.stack([o.spec_to_grid(S[b], 1) for b in range(2)]))
+    ref = np.stack([o.spec_to_grid(S[b], 1) for b in range(2)])
+    for fused in (1, 0):
+        sp.set_fused(fused)
+        ok(sp.spec_to_grid(junk, 1), ref)
     # Im(m'=0) is dropped by fourier_inv (fourier.f90:34-36)
     junk = S.copy(); junk[:, :, 0] += 3.0j
-    ok(sp.spec_to_grid(junk, 1), np.stack([o.spec_to_grid(S[b], 1) for b in range(2)]))
+    for fused in (1, 0):
+        sp.set_fused(fused)
+        ok(sp.spec_to_grid(junk, 1), ref)
 
 
 def test_max_batch_enforced(plans):
@@ -136,8 +145,8 @@ def test_max_batch_enforced(plans):
         sp.grid_to_spec(np.zeros((257,) + sp.grid_shape))
 
 
-@pytest.mark.parametrize("tag,nb", [("t30", 6144), ("t63", 1536)])
-def test_full_size_device_resident(tag, nb, oracle_factory):
+@pytest.mark.parametrize("tag,nb,fused", [("t30", 6144, 1), ("t30", 6143, 1), ("t30", 6144, 0), ("t63", 1536, 0)])
+def test_full_size_device_resident(tag, nb, fused, oracle_factory):
     """BASELINE sizes (B=6144 at T30, 1536 at T63; ~226 MB of grid data), device-resident path on
     torch's stream.  Checked against the oracle on a strided sample of fields plus two
     size-independent properties over the whole batch: linearity and batch independence."""
@@ -145,11 +154,12 @@ def test_full_size_device_resident(tag, nb, oracle_factory):
     import speedy_f90_amd as s
     o = oracle_factory(tag)
     sp = s.Spectral(tag, kx=8, max_batch=nb, device=0)
+    sp.set_fused(fused)
     sp.use_torch_stream()
     uniq = 64
     G = synth.grids(uniq, sp.ix, sp.il, first=7000)
-    reps = nb // uniq
-    dG = torch.from_numpy(G).cuda().repeat(reps, 1, 1).contiguous()
+    reps = (nb + uniq - 1) // uniq
+    dG = torch.from_numpy(G).cuda().repeat(reps, 1, 1)[:nb].contiguous()
     scale = torch.arange(1, nb + 1, dtype=torch.float64, device="cuda").view(nb, 1, 1) / nb
     dG = dG * scale                                   # every field distinct
     dS = torch.zeros((nb, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
@@ -163,7 +173,7 @@ def test_full_size_device_resident(tag, nb, oracle_factory):
         ok(hG2[b], o.spec_to_grid(hS[b], 1))
     # batch independence + linearity: field b is (b+1)/nb times its template field
     base = hS[:uniq] / (np.arange(1, uniq + 1).reshape(-1, 1, 1) / nb)
-    rel = np.abs(hS / (np.arange(1, nb + 1).reshape(-1, 1, 1) / nb) - np.tile(base, (reps, 1, 1)))
+    rel = np.abs(hS / (np.arange(1, nb + 1).reshape(-1, 1, 1) / nb) - np.tile(base, (reps, 1, 1))[:nb])
     assert rel.max() <= 1e-12 * np.abs(base).max()
     # T(a*x + y) = a*T(x) + T(y)
     a = 0.37
@@ -215,6 +225,11 @@ def test_device_ops_and_profile(oracle_factory):
     for _ in range(3):
         sp.grid_to_spec_dev(dG, s2); sp.spec_to_grid_dev(s2, g2)
     prof = sp.get_profile()
-    assert all(prof[k][1] == 3 and prof[k][0] > 0 for k in sp.KERNEL_KINDS)
+    assert all(prof[k][1] == 3 and prof[k][0] > 0 for k in sp.KERNEL_KINDS[:4])     # small batch: 4-kernel path
+    sp.set_fused(1)
+    for _ in range(2):
+        sp.grid_to_spec_dev(dG, s2); sp.spec_to_grid_dev(s2, g2)
+    prof = sp.get_profile()
+    assert prof["s2g_fused"][1] == 2 and prof["g2s_fused"][1] == 2 and prof["fourier_inv"][1] == 0
     sp.set_profiling(False)
     sp.close()
