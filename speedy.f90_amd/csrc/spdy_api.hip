@@ -123,6 +123,31 @@ void build_mfma_tables(const HostTables &t, int ks_inv, int jt, int nt_dir, int 
         }
 }
 
+// A fragments for v_mfma_f64_4x4x4_4b_f64 with both parities packed into one instruction
+// (block = (lane>>2)&3, A row i = lane&3, k = lane>>4; blocks 0,1 -> even-n sums, 2,3 -> odd-n sums).
+void build_packed_tables(const HostTables &t, int ks_inv, int js_dir, std::vector<double> &inv2, std::vector<double> &dir2)
+{
+    const int mx = t.mx, nx = t.nx, iy = t.iy;
+    auto P = [&](int m, int n, int j) { return t.poly[m + mx * (n + (size_t)nx * j)]; };
+    inv2.assign((size_t)mx * ks_inv * 64, 0.0);
+    dir2.assign((size_t)mx * js_dir * 64, 0.0);
+    for (int m = 0; m < mx; ++m) {
+        for (int ks = 0; ks < ks_inv; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int blk = (lane >> 2) & 3, i = lane & 3, k = lane >> 4, par = blk >> 1;
+                const int lat = 16 + 4 * (blk & 1) + i, n = 2 * (4 * ks + k) + par;
+                if (lat < iy && n < nx && m + n <= t.trunc + 1) inv2[((size_t)m * ks_inv + ks) * 64 + lane] = P(m, n, lat);
+            }
+        for (int ks = 0; ks < js_dir; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int blk = (lane >> 2) & 3, i = lane & 3, k = lane >> 4, par = blk >> 1;
+                const int n = 2 * (4 * (blk & 1) + i) + par, lat = 4 * ks + k;
+                if (lat < iy && n <= t.trunc && m + n <= t.trunc + 1)
+                    dir2[((size_t)m * js_dir + ks) * 64 + lane] = P(m, n, lat) * t.wt[lat];
+            }
+    }
+}
+
 int upload_all(spdy_plan *p)
 {
     HostTables &t = p->tab;
@@ -138,6 +163,12 @@ int upload_all(spdy_plan *p)
     int rc;
 #define UP(vec, field) if ((rc = dev_upload(p, vec, &d.field))) return rc
     UP(inv, pa_inv); UP(dir, pa_dir); UP(t.cosgr, cosgr); UP(t.cosgr2, cosgr2);
+    d.pa_inv2 = d.pa_dir2 = nullptr;
+    if (t.trunc == 30) {
+        std::vector<double> inv2, dir2;
+        build_packed_tables(t, d.ks_inv, d.js_dir, inv2, dir2);
+        UP(inv2, pa_inv2); UP(dir2, pa_dir2);
+    }
     UP(t.el2, el2); UP(t.elm2, elm2); UP(t.trfilt, trfilt); UP(t.gradx, gradx); UP(t.gradym, gradym);
     UP(t.gradyp, gradyp); UP(t.uvdx, uvdx); UP(t.uvdym, uvdym); UP(t.uvdyp, uvdyp); UP(t.vddym, vddym);
     UP(t.vddyp, vddyp);

@@ -14,6 +14,9 @@ struct DevPlan {
     int js_dir;    // k-steps (of 4 latitudes) in the direct transform (iy/4)
     const double *pa_inv;   // [mx][2][ks_inv][jt][64]      P(m,n,j)            MFMA A fragments
     const double *pa_dir;   // [mx][2][nt_dir][js_dir][64]  P(m,n,j)*wt(j)      MFMA A fragments
+    // 4x4x4-block fragments with both parities packed (fused T30 kernels; nullptr otherwise):
+    const double *pa_inv2;  // [mx][ks_inv][64]  blocks 0,1: latitudes 16..23 of even n; blocks 2,3: of odd n
+    const double *pa_dir2;  // [mx][js_dir][64]  blocks 0,1: n rows 0..7 of even n; blocks 2,3: of odd n
     const double *cosgr;    // [il]
     const double *cosgr2;   // [il]
     // spectral operator tables, each [nx][mx] (gradx: [mx])
