@@ -128,11 +128,7 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = max(wall, e0.elapsed_time(e1) / 1e3)
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = s.sharding.max_over_ranks(max(wall, e0.elapsed_time(e1) / 1e3), dev)
 
     # per-kernel launch durations: HIP events on the launch stream, outside the timed region
     sp.set_profiling(True)

@@ -11,3 +11,4 @@ The directory name contains a dot, so import it through the repo-root shim
 """
 from ._lib import LIB_PATH, SpdyError, build, load  # noqa: F401
 from .spectral import RESOLUTIONS, Spectral  # noqa: F401
+from . import sharding  # noqa: F401

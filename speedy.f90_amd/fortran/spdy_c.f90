@@ -1,0 +1,163 @@
+!> ISO_C_BINDING interfaces to the C ABI of include/spdy.h (libspdy.so).
+!  One-to-one with the header; complex(c_double_complex) arrays are passed where the C side
+!  takes `double*` of interleaved (re,im) pairs -- the storage is identical.
+module spdy_c
+    use iso_c_binding
+    implicit none
+    public
+
+    interface
+        function spdy_plan_create(trunc, ix, iy, kx, max_batch, device, plan) bind(C, name="spdy_plan_create") result(rc)
+            import :: c_int, c_ptr
+            integer(c_int), value :: trunc, ix, iy, kx, max_batch, device
+            type(c_ptr), intent(out) :: plan
+            integer(c_int) :: rc
+        end function
+        function spdy_plan_destroy(plan) bind(C, name="spdy_plan_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int) :: rc
+        end function
+        function spdy_last_error() bind(C, name="spdy_last_error") result(msg)
+            import :: c_ptr
+            type(c_ptr) :: msg
+        end function
+        function spdy_get_table(plan, name, buf, cap) bind(C, name="spdy_get_table") result(rc)
+            import :: c_int, c_ptr, c_char, c_double
+            type(c_ptr), value :: plan
+            character(kind=c_char), intent(in) :: name(*)
+            real(c_double), intent(out) :: buf(*)
+            integer(c_int), value :: cap
+            integer(c_int) :: rc
+        end function
+        function spdy_spec_to_grid(plan, spec, kcos, grid) bind(C, name="spdy_spec_to_grid") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            complex(c_double_complex), intent(in) :: spec(*)
+            integer(c_int), value :: kcos
+            real(c_double), intent(out) :: grid(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_grid_to_spec(plan, grid, spec) bind(C, name="spdy_grid_to_spec") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            real(c_double), intent(in) :: grid(*)
+            complex(c_double_complex), intent(out) :: spec(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_spec_to_grid_batch(plan, nb, spec, kcos, grid) bind(C, name="spdy_spec_to_grid_batch") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(in) :: spec(*)
+            integer(c_int), intent(in) :: kcos(*)
+            real(c_double), intent(out) :: grid(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_grid_to_spec_batch(plan, nb, grid, spec) bind(C, name="spdy_grid_to_spec_batch") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            real(c_double), intent(in) :: grid(*)
+            complex(c_double_complex), intent(out) :: spec(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_laplacian(plan, nb, a, o) bind(C, name="spdy_laplacian") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(in) :: a(*)
+            complex(c_double_complex), intent(out) :: o(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_inverse_laplacian(plan, nb, a, o) bind(C, name="spdy_inverse_laplacian") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(in) :: a(*)
+            complex(c_double_complex), intent(out) :: o(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_trunct(plan, nb, a) bind(C, name="spdy_trunct") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(inout) :: a(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_grad(plan, nb, psi, psdx, psdy) bind(C, name="spdy_grad") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(in) :: psi(*)
+            complex(c_double_complex), intent(inout) :: psdx(*), psdy(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_vds(plan, nb, ucosm, vcosm, vorm, divm) bind(C, name="spdy_vds") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(in) :: ucosm(*), vcosm(*)
+            complex(c_double_complex), intent(inout) :: vorm(*), divm(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_uvspec(plan, nb, vorm, divm, ucosm, vcosm) bind(C, name="spdy_uvspec") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            complex(c_double_complex), intent(in) :: vorm(*), divm(*)
+            complex(c_double_complex), intent(inout) :: ucosm(*), vcosm(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_vdspec(plan, nb, ug, vg, vorm, divm, kcos) bind(C, name="spdy_vdspec") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb, kcos
+            real(c_double), intent(in) :: ug(*), vg(*)
+            complex(c_double_complex), intent(out) :: vorm(*), divm(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_hdiff(plan, nlev, field, fdt_in, dmp, dmp1, fdt_out) bind(C, name="spdy_hdiff") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nlev
+            complex(c_double_complex), intent(in) :: field(*), fdt_in(*)
+            real(c_double), intent(in) :: dmp(*), dmp1(*)
+            complex(c_double_complex), intent(out) :: fdt_out(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_implicit_init(plan, dt) bind(C, name="spdy_implicit_init") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: plan
+            real(c_double), value :: dt
+            integer(c_int) :: rc
+        end function
+        function spdy_implicit_terms(plan, divdt, tdt, psdt) bind(C, name="spdy_implicit_terms") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            complex(c_double_complex), intent(inout) :: divdt(*), tdt(*), psdt(*)
+            integer(c_int) :: rc
+        end function
+    end interface
+
+contains
+    !> The reference has no status returns (it `stop`s on fatal errors, e.g. matrix_inversion.f90:26);
+    !  the drop-in keeps the signatures and turns a non-zero C status into `error stop`.
+    subroutine spdy_check(rc, what)
+        integer(c_int), intent(in) :: rc
+        character(*), intent(in) :: what
+        character(kind=c_char), pointer :: msg(:)
+        type(c_ptr) :: cmsg
+        integer :: n
+        if (rc >= 0) return
+        cmsg = spdy_last_error()
+        call c_f_pointer(cmsg, msg, [512])
+        n = 0
+        do while (n < 512)
+            if (msg(n + 1) == c_null_char) exit
+            n = n + 1
+        end do
+        write (*, '(3A,I0,2A)') 'spdy: ', what, ' failed (', rc, '): ', transfer(msg(1:n), repeat(' ', n))
+        error stop 'spdy: HIP spectral-transform path failed'
+    end subroutine
+end module

@@ -1,0 +1,19 @@
+!> Minimal stand-ins for the HOST MODEL's `types` and `params` modules, used only to build and
+!  test the drop-in inside this repository (tests/test_fortran_dropin.py).  In a real integration
+!  these two modules are the model's own (source/types.f90, source/params.f90) and this file is
+!  not compiled.  Resolution is chosen with -DSPDY_T63 (default T30), like editing params.f90.
+module types
+    use iso_fortran_env, only: real64
+    implicit none
+    integer, parameter :: p = real64
+end module
+
+module params
+    implicit none
+#ifdef SPDY_T63
+    integer, parameter :: trunc = 63, ix = 192, iy = 48
+#else
+    integer, parameter :: trunc = 30, ix = 96, iy = 24
+#endif
+    integer, parameter :: il = 2*iy, kx = 8, nx = trunc + 2, mx = trunc + 1
+end module

@@ -114,7 +114,7 @@ def test_product_does_not_touch_oracle():
         if os.path.basename(dirpath) in ("build", "__pycache__"):
             continue
         for f in files:
-            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".f90", "Makefile")):
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".inc", ".h", ".f90", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.lower().replace("oracle/ in any form", ""), os.path.join(dirpath, f)
 
