@@ -149,7 +149,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.res, {}).get(dom)
+                per_field = json.load(open(tpath)).get(args.res, {}).get(dom)
+                traffic = per_field * nb if per_field else None
             except Exception:
                 traffic = None
         res = {

@@ -32,6 +32,7 @@ struct spdy_plan {
     double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
     int num_cu = 256;
+    int wg_per_cu = 2;                // resident fused workgroups per CU this plan may launch (1 lets two plans share a CU)
     int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
@@ -324,6 +325,7 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
             if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
                 p->num_cu = prop.multiProcessorCount;
             if (const char *env = getenv("SPDY_FUSED")) p->fused_mode = atoi(env);
+            if (const char *env = getenv("SPDY_WG_PER_CU")) p->wg_per_cu = atoi(env) == 1 ? 1 : 2;
         }
         if (!rc) rc = upload_all(p);
         if (rc) {
@@ -426,7 +428,7 @@ int spdy_spec_to_grid_dev(spdy_plan *p, int nb, const double *d_spec, const int 
     if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
     if (use_fused(p, nb))
         return timed(p, SPDY_K_S2G_FUSED, [&] {
-            return spdy::launch_s2g_fused(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu, p->stream);
+            return spdy::launch_s2g_fused(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu * p->wg_per_cu, p->stream);
         });
     RC(timed(p, SPDY_K_LEGENDRE_INV, [&] { return spdy::launch_legendre_inv(p->dev, nb, d_spec, p->four, p->stream); }));
     RC(timed(p, SPDY_K_FOURIER_INV, [&] { return spdy::launch_fourier_inv(p->dev, nb, p->four, d_kcos, kcos_all, d_grid, p->stream); }));
@@ -440,7 +442,7 @@ int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_
     if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
     if (use_fused(p, nb))
         return timed(p, SPDY_K_G2S_FUSED, [&] {
-            return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu, p->stream);
+            return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu * p->wg_per_cu, p->stream);
         });
     RC(timed(p, SPDY_K_FOURIER_DIR, [&] { return spdy::launch_fourier_dir(p->dev, nb, d_grid, nullptr, p->four, p->stream); }));
     RC(timed(p, SPDY_K_LEGENDRE_DIR, [&] { return spdy::launch_legendre_dir(p->dev, nb, p->four, d_spec, p->stream); }));
@@ -573,8 +575,8 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
     RC(check_batch(p, nb));
     const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
     if (use_fused(p, nb)) {
-        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, p->stage_c, p->num_cu, p->stream));
-        KERNEL(spdy::launch_g2s_fused(p->dev, nb, vg, sc, p->stage_d, p->num_cu, p->stream));
+        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, p->stage_c, p->num_cu * p->wg_per_cu, p->stream));
+        KERNEL(spdy::launch_g2s_fused(p->dev, nb, vg, sc, p->stage_d, p->num_cu * p->wg_per_cu, p->stream));
         KERNEL(spdy::launch_vds(p->dev, nb, p->stage_c, p->stage_d, vorm, divm, p->stream));
         return SPDY_OK;
     }

@@ -43,10 +43,10 @@ hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, cons
 hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, const double *gscale, double *four,
                               hipStream_t s);
 
-// Fused persistent T30 kernels (whole transform in one pass through LDS; num_cu workgroups)
+// Fused persistent T30 kernels (whole transform in one pass through LDS; at most max_wg workgroups)
 hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid,
-                            int num_cu, hipStream_t s);
-hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int num_cu,
+                            int max_wg, hipStream_t s);
+hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg,
                             hipStream_t s);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };
