@@ -32,7 +32,7 @@ struct spdy_plan {
     double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
     int num_cu = 256;
-    int wg_per_cu = 2;                // resident fused workgroups per CU this plan may launch (1 lets two plans share a CU)
+    int wg_per_cu = 1;                // fused kernels: one 448-thread wave-specialised workgroup per CU
     int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
@@ -325,7 +325,7 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
             if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
                 p->num_cu = prop.multiProcessorCount;
             if (const char *env = getenv("SPDY_FUSED")) p->fused_mode = atoi(env);
-            if (const char *env = getenv("SPDY_WG_PER_CU")) p->wg_per_cu = atoi(env) == 1 ? 1 : 2;
+            if (const char *env = getenv("SPDY_WG_PER_CU")) p->wg_per_cu = atoi(env) >= 1 ? atoi(env) : 1;
         }
         if (!rc) rc = upload_all(p);
         if (rc) {
