@@ -63,8 +63,8 @@ int spdy_plan_synchronize(spdy_plan *plan);
 enum { SPDY_K_LEGENDRE_INV = 0, SPDY_K_FOURIER_INV = 1, SPDY_K_FOURIER_DIR = 2, SPDY_K_LEGENDRE_DIR = 3,
        SPDY_K_S2G_FUSED = 4, SPDY_K_G2S_FUSED = 5, SPDY_K_COUNT = 6 };
 int spdy_plan_set_profiling(spdy_plan *plan, int on);
-/* Kernel selection for the transforms: 1 = fused single-pass kernels (T30; default when the batch is
- * large enough to fill the chip), 0 = the four-kernel path (any resolution), -1 = automatic.    */
+/* Kernel selection for the transforms: 1 / -1 (default) = fused single-pass kernels where the resolution
+ * has them (T30), 0 = force the four-kernel path (any resolution; what T63 always uses).          */
 int spdy_plan_set_fused(spdy_plan *plan, int mode);
 int spdy_plan_get_profile(spdy_plan *plan, double *ms, int *launches);
 /* dims[0..7] = trunc, ix, iy, il, kx, nx, mx, max_batch */

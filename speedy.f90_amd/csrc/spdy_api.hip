@@ -264,12 +264,13 @@ int sync(spdy_plan *p)
 
 // Launch one transform kernel; when profiling is on, bracket it with HIP events recorded on
 // the very stream it runs on (kind: SPDY_K_*).
-// Fused single-pass kernels exist for T30; they need enough tiles (4 fields each) to occupy the CUs.
+// Fused single-pass kernels exist for T30.  Measured on MI355X (tools/small_batch.sh) they beat the
+// four-kernel path at every batch size (one launch and no HBM intermediate: 2x even at 8..91 fields), so
+// "auto" means fused whenever the resolution has them.
 bool use_fused(const spdy_plan *p, int nb)
 {
-    if (p->tab.trunc != 30 || p->fused_mode == 0) return false;
-    if (p->fused_mode == 1) return true;
-    return nb >= 2 * p->num_cu;      // >= half a tile per CU; below that the 4-kernel path spreads better
+    (void)nb;
+    return p->tab.trunc == 30 && p->fused_mode != 0;
 }
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)

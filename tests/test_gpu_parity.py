@@ -222,11 +222,12 @@ def test_device_ops_and_profile(oracle_factory):
     sp.set_profiling(True)
     g2 = torch.zeros_like(dG)
     s2 = torch.zeros_like(dS)
+    sp.set_fused(0)
     for _ in range(3):
         sp.grid_to_spec_dev(dG, s2); sp.spec_to_grid_dev(s2, g2)
     prof = sp.get_profile()
-    assert all(prof[k][1] == 3 and prof[k][0] > 0 for k in sp.KERNEL_KINDS[:4])     # small batch: 4-kernel path
-    sp.set_fused(1)
+    assert all(prof[k][1] == 3 and prof[k][0] > 0 for k in sp.KERNEL_KINDS[:4])     # forced four-kernel path
+    sp.set_fused(-1)                                                                  # auto = fused at T30
     for _ in range(2):
         sp.grid_to_spec_dev(dG, s2); sp.spec_to_grid_dev(s2, g2)
     prof = sp.get_profile()
