@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Debug helper (GPU box): per-phase cycle counts of the fused T30 kernels, workgroup 0.
-Needs the trace build:  hipcc ... -DSPDY_PHASE_TRACE -> speedy.f90_amd/build_dbg/libspdy_trace.so"""
+Needs the trace build:  make -C speedy.f90_amd trace  (-> build_dbg/libspdy_trace.so)
+Marks: see the PHASE_MARK(kernel, mark) calls in csrc/spdy_fused_t30.inc"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +10,7 @@ import torch
 import speedy_f90_amd as s
 from importlib import import_module
 lib_mod = import_module("speedy_f90_amd._lib")
-lib_mod.LIB_PATH = os.path.join(ROOT, "speedy.f90_amd", "build_dbg", "libspdy_trace.so")
+lib_mod.LIB_PATH = os.environ.get("SPDY_TRACE_LIB", os.path.join(ROOT, "speedy.f90_amd", "build_dbg", "libspdy_trace.so"))
 s.LIB_PATH = lib_mod.LIB_PATH
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
 sp = s.Spectral("t30", max_batch=nb, device=0)
@@ -20,21 +21,37 @@ o = torch.zeros_like(g)
 for _ in range(3):
     sp.grid_to_spec_dev(g, sc); sp.spec_to_grid_dev(sc, o)
 torch.cuda.synchronize()
-buf = np.zeros(2 * 8 * 8 * 4, np.int64)
+buf = np.zeros(2 * 8 * 8 * 8, np.int64)
 sp.lib.spdy_debug_phase_trace(buf.ctypes.data_as(ctypes.c_void_p))
-t = buf.reshape(2, 8, 8, 4)   # kernel, tile iter, mark, wave
-names = [["top", "bar0", "staged+bar", "L done", "bar", "fft done", "copyout done", "-"],
-         ["top", "bar0", "staged+bar", "fft done", "final done", "bar", "L done", "prefetch issued"]]
+t = buf.reshape(2, 8, 8, 8)[..., :8]   # kernel, step, mark, wave (0-3 Legendre, 4-6 FFT)
 for k, kn in enumerate(("s2g_fused", "g2s_fused")):
-    print("==", kn, "(cycles since tile top, per wave; tile iterations 1..4)")
+    print("==", kn, "(cycles since the earliest mark of the step, per wave; steps 1..4; -1 = mark not hit)")
     for it in range(1, 5):
-        base = t[k, it, 0].min()
-        nxt = t[k, it + 1, 0].min() if it + 1 < 8 and t[k, it + 1, 0].min() > 0 else 0
-        print(" tile iter %d  total %s" % (it, (nxt - base) if nxt else "?"))
+        live = t[k, it][t[k, it] > 0]
+        if not live.size:
+            continue
+        base = live.min()
+        nl = t[k, it + 1][t[k, it + 1] > 0]
+        print(" step %d  total %s" % (it, int(nl.min() - base) if nl.size else "?"))
         for m in range(8):
-            print("   %-16s" % names[k][m], " ".join("%6d" % (v - base) for v in t[k, it, m]))
+            if (t[k, it, m] > 0).any():
+                print("   mark %d " % m, " ".join("%6d" % (v - base if v > 0 else -1) for v in t[k, it, m]))
+
+# whole-kernel timeline (workgroup 0 and the last one): entry, top of every step, exit -- in s_memtime ticks
+tl = np.zeros(2 * 2 * 8 * 32, np.int64)
+sp.lib.spdy_debug_timeline(tl.ctypes.data_as(ctypes.c_void_p))
+tl = tl.reshape(2, 2, 8, 32)
 for k, kn in enumerate(("s2g_fused", "g2s_fused")):
-    tops = [t[k, it, 0].min() for it in range(8) if t[k, it, 0].min() > 0]
-    print(kn, "tile-to-tile (cycles):", [int(b - a) for a, b in zip(tops[:-1], tops[1:])])
-    ends = [t[k, it, m][t[k, it, m] > 0].max() for it in range(8) for m in (6, 7) if (t[k, it, m] > 0).any()]
-    print(kn, "first top -> last mark:", int(max(ends) - tops[0]), "cycles over", len(tops), "tiles")
+    for b in range(2):
+        print("== timeline", kn, "workgroup", "0" if b == 0 else "last")
+        for wv, role in ((0, "Legendre wave 0"), (4, "FFT wave 4")):
+            row = tl[k, b, wv]
+            t0 = row[0]
+            tops = [int(v - t0) for v in row[1:26] if v > 0]
+            pro = [int(v - t0) if v > 0 else -1 for v in row[26:31]]
+            print("   %-16s entry 0 | prologue marks %s | step tops %s | exit %d" % (role, pro, tops, int(row[31] - t0)))
+# the same launches timed with events, for the tick rate
+sp.set_profiling(True)
+for _ in range(5):
+    sp.grid_to_spec_dev(g, sc); sp.spec_to_grid_dev(sc, o)
+print({k: v[0] / max(v[1], 1) for k, v in sp.get_profile().items() if v[1]})
