@@ -64,6 +64,42 @@ def cpu_baseline(res, sample_fields=256, target_s=10.0):
                       "time), %.1f s on one core of %d" % (nrep, sample_fields, res.upper(), dt, os.cpu_count() or 1)}
 
 
+def cpu_baseline_all_cores(res, per_thread_fields=64, target_s=5.0):
+    """The same reference path on every host core at once: one thread per core, each transforming its own
+    fields one at a time (the calls release the GIL; the reference's tables are read-only after init).
+    This is the 'whole host' number next to the single-core one -- the reference itself is single-threaded."""
+    import threading
+    import synth
+    from oracle.pyoracle import Oracle, Reference, RESOLUTIONS
+    if Reference.available(res):
+        impl, kind = Reference(res), "reference"
+    else:
+        impl, kind = Oracle(*RESOLUTIONS[res]), "port"
+    nthr = os.cpu_count() or 1
+    G = synth.grids(per_thread_fields, impl.ix, impl.il, first=0)
+    t0 = time.perf_counter()
+    ref_out = impl.roundtrip_loop(G, 1)
+    one = time.perf_counter() - t0
+    nrep = max(1, int(target_s / max(one, 1e-6)))
+    outs = [None] * nthr
+
+    def work(i):
+        outs[i] = impl.roundtrip_loop(G, nrep)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    same = all(o is not None and np.array_equal(o, ref_out) for o in outs)
+    return {"value": nthr * per_thread_fields * nrep / dt, "unit": "round trips/s", "cores": nthr, "kind": kind,
+            "threads_agree_with_single_thread": bool(same),
+            "sample": "%d threads x %d passes over %d synthetic %s fields each, %.1f s wall"
+                      % (nthr, nrep, per_thread_fields, res.upper(), dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +209,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.res)
             res["gpu_over_cpu_core"] = value / res["cpu_baseline"]["value"]
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.res)
+            res["gpu_over_cpu_all_cores"] = value / res["cpu_baseline_all_cores"]["value"]
         print(json.dumps(res))
     sp.close()
     if dist:
