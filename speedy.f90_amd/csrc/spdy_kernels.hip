@@ -194,34 +194,60 @@ __device__ __forceinline__ void sub48_forward(double (&x)[48], double (&y)[48])
 // Block = 64 rows x TPR lanes-per-row; thread = h*64 + r, so h (which 48-point column of the
 // ido=48 stage this lane owns) is wave-uniform.
 // ------------------------------------------------------------------------------------------
-constexpr int FFT_ROWS = 64;
+// rows per block: the LDS tile (rows x (N+1) doubles) decides how many blocks share a CU -- at N = 192 a
+// 64-row tile is 98.8 KB (one block, 4 waves per CU: load, FFT and store phases cannot overlap); 32 rows
+// give 3 blocks per CU.  (SPDY_FFT_ROWS_192 for experiments.)
+#ifndef SPDY_FFT_ROWS_192
+#define SPDY_FFT_ROWS_192 32
+#endif
+constexpr int fft_rows(int nf) { return nf == 192 ? SPDY_FFT_ROWS_192 : 64; }
 
 template <int NF, int TWO_MX>
-__global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_inv_kernel(
+__global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_inv_kernel(
     const double *__restrict__ four, double *__restrict__ grid, const double *__restrict__ cosgr,
     const int *__restrict__ d_kcos, int kcos_all, int nrows, int il, int fs)
 {
-    constexpr int TPR = NF / 48, RS = NF + 1, NT = FFT_ROWS * TPR;
+    constexpr int FFT_ROWS = fft_rows(NF), TPR = NF / 48, RS = NF + 1, NT = FFT_ROWS * TPR;
     constexpr int LASTF = TWO_MX - 2;   // fvar[i] = F[i+1] for 1 <= i <= LASTF, zero beyond
+    constexpr int PER_ROW = (TWO_MX + 15) / 16 * 8, NPRE = FFT_ROWS * PER_ROW / NT;   // 16-byte pieces per row (= fs/2), per thread
+    static_assert(FFT_ROWS * PER_ROW % NT == 0, "whole pieces per thread");
     __shared__ double tile[FFT_ROWS * RS];
+    __shared__ double tw[(TPR - 1) * 48];   // ido=48 twiddles: the index depends on the lane's column h -> LDS, not scalar loads
     const int tid = threadIdx.x, r = tid & (FFT_ROWS - 1), h = tid / FFT_ROWS;
-    const long row0 = (long)blockIdx.x * FFT_ROWS;
+    const int ntiles = (nrows + FFT_ROWS - 1) / FFT_ROWS;
+    for (int e = tid; e < (TPR - 1) * 48; e += NT) tw[e] = fftc<NF>().first[e];
+
+    // The block walks over row tiles; the next tile's Fourier rows are fetched into registers (16 B per lane,
+    // coalesced) while the current one is transformed: with one wave per 16 rows and 24 KB of LDS per wave only
+    // ~6 waves fit a CU, so the loads have to overlap the arithmetic inside the wave.
+    double2 pre[NPRE];
+#define FINV_FETCH(tile_)                                                                          \
+    do {                                                                                           \
+        const long r0_ = (long)(tile_) * FFT_ROWS;                                                 \
+        const double2 *src_ = reinterpret_cast<const double2 *>(four + r0_ * fs);                  \
+        const long lim_ = ((long)nrows - r0_) * PER_ROW; /* pieces of rows that exist */           \
+        UNROLL for (int i = 0; i < NPRE; ++i) {                                                    \
+            const int e_ = tid + i * NT;                                                           \
+            pre[i] = e_ < lim_ ? src_[e_] : make_double2(0.0, 0.0);                                \
+        }                                                                                          \
+    } while (0)
+    if ((int)blockIdx.x < ntiles) FINV_FETCH(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = (long)t * FFT_ROWS;
     const int nvalid = (int)min((long)FFT_ROWS, (long)nrows - row0);
 
-    // phase 1: coalesced load of the Fourier rows (first TWO_MX doubles of each fs-stride row)
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(four + row0 * fs);
-        const int per_row = fs / 2;
-        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
-            const int rr = e / per_row, c2 = e - rr * per_row;
-            if (2 * c2 < TWO_MX) {
-                double2 v = make_double2(0.0, 0.0);
-                if (rr < nvalid) v = src[e];
-                tile[rr * RS + 2 * c2] = v.x;
-                tile[rr * RS + 2 * c2 + 1] = v.y;
-            }
+    // phase 1: the prefetched Fourier rows (first TWO_MX doubles of each fs-stride row) into the LDS tile
+    __syncthreads();                                       // previous tile's store phase is done with the LDS tile
+    int tl = tid;
+    asm volatile("" : "+v"(tl));                           // per tile: 2 x NPRE hoisted LDS offsets would spill next to the FFT
+    UNROLL for (int i = 0; i < NPRE; ++i) {
+        const int e = tl + i * NT, rr = e / PER_ROW, c2 = e - rr * PER_ROW;
+        if (2 * c2 < TWO_MX) {
+            tile[rr * RS + 2 * c2] = pre[i].x;
+            tile[rr * RS + 2 * c2 + 1] = pre[i].y;
         }
     }
+    if (t + (int)gridDim.x < ntiles) FINV_FETCH(t + gridDim.x);
     __syncthreads();
 
     // phase 2: ido=48 stage (this lane's column h only), then the 48-point sub-transform
@@ -268,7 +294,7 @@ __global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_inv_kernel(
                 } else {
                     const double cr = h == 1 ? tr1 - tr4 : h == 2 ? tr2 - tr3 : tr1 + tr4;
                     const double ci = h == 1 ? ti1 + ti4 : h == 2 ? ti2 - ti3 : ti1 - ti4;
-                    const double wr = c.first[48 * (h - 1) + p - 1], wi = c.first[48 * (h - 1) + p];
+                    const double wr = tw[48 * (h - 1) + p - 1], wi = tw[48 * (h - 1) + p];
                     x[p] = wr * cr - wi * ci;
                     x[p + 1] = wr * ci + wi * cr;
                 }
@@ -308,40 +334,58 @@ __global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_inv_kernel(
             }
         }
     }
+    }   // tile loop
+#undef FINV_FETCH
 }
 
 // ------------------------------------------------------------------------------------------
 // fourier_dir  (fourier.f90:56-82 + fftpack rfftf1): grid[nb*il][NF] -> four[nb*il][fs]
 // ------------------------------------------------------------------------------------------
 template <int NF, int TWO_MX>
-__global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_dir_kernel(
+__global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel(
     const double *__restrict__ grid, const double *__restrict__ gscale, double *__restrict__ four,
     int nrows, int il, int fs)
 {
-    constexpr int TPR = NF / 48, RS = NF + 1, NT = FFT_ROWS * TPR;
+    constexpr int FFT_ROWS = fft_rows(NF), TPR = NF / 48, RS = NF + 1, NT = FFT_ROWS * TPR;
+    constexpr int PER_ROW = NF / 2, NPRE = FFT_ROWS * PER_ROW / NT;   // 16-byte pieces per grid row, per thread
+    static_assert(FFT_ROWS * PER_ROW % NT == 0, "whole pieces per thread");
     __shared__ double tile[FFT_ROWS * RS];
+    __shared__ double tw[(TPR - 1) * 48];   // ido=48 twiddles, indexed per lane in phase 3 -> LDS, not constant-memory vector loads
     const int tid = threadIdx.x, r = tid & (FFT_ROWS - 1), h = tid / FFT_ROWS;
-    const long row0 = (long)blockIdx.x * FFT_ROWS;
-    const int nvalid = (int)min((long)FFT_ROWS, (long)nrows - row0);
+    const int ntiles = (nrows + FFT_ROWS - 1) / FFT_ROWS;
     const FftConstants &c = fftc<NF>();
+    for (int e = tid; e < (TPR - 1) * 48; e += NT) tw[e] = c.first[e];
 
-    // phase 1: coalesced load of 64 grid rows (optionally scaled per latitude: vdspec)
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(grid + row0 * NF);
-        constexpr int per_row = NF / 2;
-        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
-            const int rr = e / per_row, c2 = e - rr * per_row;
-            double2 v = make_double2(0.0, 0.0);
-            if (rr < nvalid) {
-                v = src[e];
-                if (gscale) {
-                    const double sc = gscale[(int)((row0 + rr) % il)];
-                    v.x *= sc; v.y *= sc;
-                }
-            }
-            tile[rr * RS + 2 * c2] = v.x;
-            tile[rr * RS + 2 * c2 + 1] = v.y;
+    // persistent over row tiles with a register prefetch of the next tile's grid rows (see fourier_inv_kernel)
+    double2 pre[NPRE];
+#define FDIR_FETCH(tile_)                                                                          \
+    do {                                                                                           \
+        const long r0_ = (long)(tile_) * FFT_ROWS;                                                 \
+        const double2 *src_ = reinterpret_cast<const double2 *>(grid + r0_ * NF);                  \
+        const long lim_ = ((long)nrows - r0_) * PER_ROW;                                           \
+        UNROLL for (int i = 0; i < NPRE; ++i) {                                                    \
+            const int e_ = tid + i * NT;                                                           \
+            pre[i] = e_ < lim_ ? src_[e_] : make_double2(0.0, 0.0);                                \
+        }                                                                                          \
+    } while (0)
+    if ((int)blockIdx.x < ntiles) FDIR_FETCH(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = (long)t * FFT_ROWS;
+    const int nvalid = (int)min((long)FFT_ROWS, (long)nrows - row0);
+
+    // phase 1: the prefetched grid rows into the LDS tile (optionally scaled per latitude: vdspec)
+    __syncthreads();                                       // previous tile's store phase is done with the LDS tile
+    int tl = tid;
+    asm volatile("" : "+v"(tl));                           // per tile: 2 x NPRE hoisted LDS offsets would spill next to the FFT
+    UNROLL for (int i = 0; i < NPRE; ++i) {
+        const int e = tl + i * NT, rr = e / PER_ROW, c2 = e - rr * PER_ROW;
+        double2 v = pre[i];
+        if (gscale) {
+            const double sc = gscale[(int)((row0 + rr) % il)];
+            v.x *= sc; v.y *= sc;
         }
+        tile[rr * RS + 2 * c2] = v.x;
+        tile[rr * RS + 2 * c2 + 1] = v.y;
     }
     __syncthreads();
 
@@ -357,6 +401,7 @@ __global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_dir_kernel(
         double *rowp = tile + r * RS + 48 * h;
         UNROLL for (int i = 0; i < 48; ++i) rowp[i] = y[i];
     }
+    if (t + (int)gridDim.x < ntiles) FDIR_FETCH(t + gridDim.x);   // the FFT registers are dead: next tile in flight during phases 3-4
     __syncthreads();
 
     // phase 3: the ido=48 stage, in place.  Butterflies p and 46-p touch the same 4*TPR slots,
@@ -370,14 +415,14 @@ __global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_dir_kernel(
                     z[0] = a0 + a1;  z[95] = a0 - a1;  z[48] = -b1;  z[47] = b0;
                 } else {
                     const int p = 2 * it - 1, q = 46 - p;
-                    const double wr = c.first[p - 1], wi = c.first[p];
+                    const double wr = tw[p - 1], wi = tw[p];
                     const double a0r = z[p], a0i = z[p + 1], a1r = z[48 + p], a1i = z[48 + p + 1];
                     const double tr2 = wr * a1r + wi * a1i, ti2 = wr * a1i - wi * a1r;
                     if (p == q) {
                         z[p + 1] = a0i + ti2;  z[48 + q + 1] = ti2 - a0i;
                         z[p] = a0r + tr2;      z[48 + q] = a0r - tr2;
                     } else {
-                        const double vr = c.first[q - 1], vi = c.first[q];
+                        const double vr = tw[q - 1], vi = tw[q];
                         const double b0r = z[q], b0i = z[q + 1], b1r = z[48 + q], b1i = z[48 + q + 1];
                         const double sr2 = vr * b1r + vi * b1i, si2 = vr * b1i - vi * b1r;
                         z[p + 1] = a0i + ti2;  z[48 + q + 1] = ti2 - a0i;
@@ -407,12 +452,12 @@ __global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_dir_kernel(
                         if (s == 1 && p == q) break;
                         const int pp = s == 0 ? p : q, qq = s == 0 ? q : p;
                         const double *a = in[s];
-                        const double cr2 = c.first[pp - 1] * a[2] + c.first[pp] * a[3];
-                        const double ci2 = c.first[pp - 1] * a[3] - c.first[pp] * a[2];
-                        const double cr3 = c.first[48 + pp - 1] * a[4] + c.first[48 + pp] * a[5];
-                        const double ci3 = c.first[48 + pp - 1] * a[5] - c.first[48 + pp] * a[4];
-                        const double cr4 = c.first[96 + pp - 1] * a[6] + c.first[96 + pp] * a[7];
-                        const double ci4 = c.first[96 + pp - 1] * a[7] - c.first[96 + pp] * a[6];
+                        const double cr2 = tw[pp - 1] * a[2] + tw[pp] * a[3];
+                        const double ci2 = tw[pp - 1] * a[3] - tw[pp] * a[2];
+                        const double cr3 = tw[48 + pp - 1] * a[4] + tw[48 + pp] * a[5];
+                        const double ci3 = tw[48 + pp - 1] * a[5] - tw[48 + pp] * a[4];
+                        const double cr4 = tw[96 + pp - 1] * a[6] + tw[96 + pp] * a[7];
+                        const double ci4 = tw[96 + pp - 1] * a[7] - tw[96 + pp] * a[6];
                         const double sr1 = cr2 + cr4, sr4 = cr4 - cr2, si1 = ci2 + ci4, si4 = ci2 - ci4;
                         const double si2 = a[1] + ci3, si3 = a[1] - ci3, sr2 = a[0] + cr3, sr3 = a[0] - cr3;
                         z[pp] = sr1 + sr2;            z[144 + qq] = sr2 - sr1;
@@ -441,6 +486,8 @@ __global__ __launch_bounds__(FFT_ROWS *(NF / 48)) void fourier_dir_kernel(
             }
         }
     }
+    }   // tile loop
+#undef FDIR_FETCH
 }
 
 // ------------------------------------------------------------------------------------------
@@ -761,11 +808,25 @@ hipError_t launch_legendre_dir(const DevPlan &p, int nb, const double *four, dou
     return hipGetLastError();
 }
 
+// persistent FFT blocks: as many as can be resident (LDS-limited: 3 per CU at ~50 KB per block)
+static int fft_grid_limit()
+{
+    static int limit = 0;
+    if (!limit) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        limit = 3 * cus;
+    }
+    return limit;
+}
+
 hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, const int *d_kcos, int kcos_all,
                               double *grid, hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
-    const int nrows = nb * p.il, nblk = (nrows + FFT_ROWS - 1) / FFT_ROWS;
+    const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
+    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, fft_grid_limit());
+    if (p.fs != (2 * p.mx + 15) / 16 * 16) return hipErrorInvalidValue;
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_inv_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, four, grid, p.cosgr,
                            d_kcos, kcos_all, nrows, p.il, p.fs);
@@ -780,7 +841,8 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
                               hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
-    const int nrows = nb * p.il, nblk = (nrows + FFT_ROWS - 1) / FFT_ROWS;
+    const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
+    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, fft_grid_limit());
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_dir_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, grid, gscale, four,
                            nrows, p.il, p.fs);
