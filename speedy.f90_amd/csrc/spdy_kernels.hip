@@ -529,37 +529,54 @@ __global__ __launch_bounds__(LEG_NT) void legendre_inv_kernel(DevPlan p, int nb,
     __syncthreads();
 
     const int m = m0 + w;
-    if (m >= p.mx) return;
-    const int kact = p.nx - m;                       // active n: 0 .. kact-1
+    const bool wvalid = m < p.mx;
+    const int kact = p.nx - min(m, p.mx - 1);        // active n: 0 .. kact-1
     d4 acc[2][JT];
     UNROLL for (int q = 0; q < 2; ++q) {
         UNROLL for (int t = 0; t < JT; ++t) acc[q][t] = (d4){0.0, 0.0, 0.0, 0.0};
     }
-    UNROLL for (int par = 0; par < 2; ++par) {
-        const int cnt = (kact + 1 - par) >> 1, nks = (cnt + 3) >> 2;
-        const double *bsrc = xs + w * wstride + par * kp * 16 + (lane >> 4) * 16 + (lane & 15);
-        const double *asrc = p.pa_inv + ((long)(m * 2 + par) * p.ks_inv) * JT * 64 + lane;
-        for (int ks = 0; ks < nks; ++ks) {
-            const double bv = bsrc[ks * 64];
-            UNROLL for (int t = 0; t < JT; ++t) {
-                const double av = asrc[(ks * JT + t) * 64];
-                acc[par][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[par][t], 0, 0, 0);
+    if (wvalid) {
+        UNROLL for (int par = 0; par < 2; ++par) {
+            const int cnt = (kact + 1 - par) >> 1, nks = (cnt + 3) >> 2;
+            const double *bsrc = xs + w * wstride + par * kp * 16 + (lane >> 4) * 16 + (lane & 15);
+            const double *asrc = p.pa_inv + ((long)(m * 2 + par) * p.ks_inv) * JT * 64 + lane;
+            // A fragments stream from L2: fetch k-step ks+1 while the matrix cores work on ks
+            double a_nxt[JT];
+            UNROLL for (int t = 0; t < JT; ++t) a_nxt[t] = asrc[t * 64];
+            for (int ks = 0; ks < nks; ++ks) {
+                double a_cur[JT];
+                UNROLL for (int t = 0; t < JT; ++t) a_cur[t] = a_nxt[t];
+                const int kn = min(ks + 1, nks - 1);
+                UNROLL for (int t = 0; t < JT; ++t) a_nxt[t] = asrc[(kn * JT + t) * 64];
+                const double bv = bsrc[ks * 64];
+                UNROLL for (int t = 0; t < JT; ++t)
+                    acc[par][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], bv, acc[par][t], 0, 0, 0);
             }
         }
     }
-    // D layout: row = (lane>>4) + 4*reg, col = lane&15
-    const int col = lane & 15, fld = b0 + (col >> 1), part = col & 1;
-    if (fld < nb) {
-        double *base = four + (long)fld * p.il * p.fs + 2 * m + part;
-        UNROLL for (int t = 0; t < JT; ++t) {
+    // Output through LDS, one 16-latitude tile (16 southern + 16 northern rows) at a time: the D layout
+    // (row = (lane>>4) + 4*reg, col = lane&15 = 2*field + re/im) would give 8-byte stores with 16 contiguous
+    // bytes each, which the memory system runs at a third of the rate of full lines (tools/store_issue.hip);
+    // the block's 8 wavenumbers make one 128-byte line per (field, latitude row).
+    // LDS image: [row 0..15 south j, 16..31 north il-1-j][field][18: 8 x (re, im) + pad]
+    const int col = lane & 15, part = col & 1;
+    UNROLL for (int t = 0; t < JT; ++t) {
+        __syncthreads();                              // the B image / the previous tile's lines are no longer needed
+        if (wvalid) {
             UNROLL for (int rg = 0; rg < 4; ++rg) {
-                const int j = 16 * t + (lane >> 4) + 4 * rg;
-                if (j < p.iy) {
-                    const double ev = acc[0][t][rg], od = acc[1][t][rg];
-                    base[(long)(p.il - 1 - j) * p.fs] = ev + od;
-                    base[(long)j * p.fs] = ev - od;
-                }
+                const int rowi = (lane >> 4) + 4 * rg;
+                const double ev = acc[0][t][rg], od = acc[1][t][rg];
+                xs[(rowi * LEG_BT + (col >> 1)) * 18 + 2 * w + part] = ev - od;           // row j
+                xs[((16 + rowi) * LEG_BT + (col >> 1)) * 18 + 2 * w + part] = ev + od;    // row il-1-j
             }
+        }
+        __syncthreads();
+        UNROLL for (int i = 0; i < 32 * LEG_BT * LEG_MG / LEG_NT; ++i) {
+            const int e = tid + i * LEG_NT, mi = e & (LEG_MG - 1), fld = (e >> 3) & (LEG_BT - 1), rowi = e >> 6;
+            const int jj = 16 * t + (rowi & 15), row = rowi < 16 ? jj : p.il - 1 - jj;
+            if (jj < p.iy && b0 + fld < nb && m0 + mi < p.mx)
+                *reinterpret_cast<double2 *>(four + ((long)(b0 + fld) * p.il + row) * p.fs + 2 * (m0 + mi)) =
+                    *reinterpret_cast<const double2 *>(xs + (rowi * LEG_BT + fld) * 18 + 2 * mi);
         }
     }
 }
@@ -573,60 +590,107 @@ template <int NTD>
 __global__ __launch_bounds__(LEG_NT) void legendre_dir_kernel(DevPlan p, int nb, const double *__restrict__ four,
                                                                double *__restrict__ spec)
 {
+    // The Fourier image of one tile (8 fields x il rows x 8 wavenumbers) fills most of the LDS, so only one block
+    // fits a CU: the block is persistent over tiles and fetches the next tile's image into registers while the
+    // matrix cores work on the current one (load, contraction and store phases would otherwise run back to back).
+    constexpr int IL = NTD == 3 ? 96 : 48;                        // launcher checks p.il
+    constexpr int NPRE = LEG_BT * IL * LEG_MG / LEG_NT;           // 16-byte pieces per thread and tile
     extern __shared__ __attribute__((aligned(16))) double fsm[];   // [w][il][16] (+2 pad per w)
-    const int wstride = p.il * 16 + 2;
+    const int wstride = IL * 16 + 2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b0 = blockIdx.x * LEG_BT, m0 = blockIdx.y * LEG_MG;
+    const int nbx = (nb + LEG_BT - 1) / LEG_BT, ntiles = nbx * ((p.mx + LEG_MG - 1) / LEG_MG);
+    double2 pre[NPRE];
+#define LDIR_FETCH(tile_)                                                                                     \
+    do {                                                                                                      \
+        const int tb0_ = ((tile_) % nbx) * LEG_BT, tm0_ = ((tile_) / nbx) * LEG_MG;                           \
+        UNROLL for (int i = 0; i < NPRE; ++i) {                                                               \
+            const int e_ = tid + i * LEG_NT, mi_ = e_ & (LEG_MG - 1), t_ = e_ >> 3, row_ = t_ % IL, b_ = t_ / IL; \
+            pre[i] = make_double2(0.0, 0.0);                                                                  \
+            if (tb0_ + b_ < nb && tm0_ + mi_ < p.mx)                                                          \
+                pre[i] = *reinterpret_cast<const double2 *>(four + ((long)(tb0_ + b_) * IL + row_) * p.fs + 2 * (tm0_ + mi_)); \
+        }                                                                                                     \
+    } while (0)
+    if ((int)blockIdx.x < ntiles) LDIR_FETCH((int)blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b0 = (tile % nbx) * LEG_BT, m0 = (tile / nbx) * LEG_MG;
+    __syncthreads();                                  // the previous tile's output lines have left the LDS
     {
-        const int total = LEG_BT * p.il * LEG_MG;
-        for (int e = tid; e < total; e += LEG_NT) {
-            const int mi = e & (LEG_MG - 1), t = e >> 3, row = t % p.il, b = t / p.il;
-            double2 v = make_double2(0.0, 0.0);
-            if (b0 + b < nb && m0 + mi < p.mx)
-                v = *reinterpret_cast<const double2 *>(four + ((long)(b0 + b) * p.il + row) * p.fs + 2 * (m0 + mi));
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                  // per tile: hoisted LDS offsets would cost 2 x NPRE registers
+        UNROLL for (int i = 0; i < NPRE; ++i) {
+            const int e = tl + i * LEG_NT, mi = e & (LEG_MG - 1), t = e >> 3, row = t % IL, b = t / IL;
             double *d = fsm + mi * wstride + row * 16 + 2 * b;
-            d[0] = v.x;
-            d[1] = v.y;
+            d[0] = pre[i].x;
+            d[1] = pre[i].y;
         }
     }
+    if (tile + (int)gridDim.x < ntiles) LDIR_FETCH(tile + (int)gridDim.x);
     __syncthreads();
 
     const int m = m0 + w;
-    if (m >= p.mx) return;
+    const bool wvalid = m < p.mx;
     // active n (0-based): n <= trunc and m + n <= trunc + 1
-    const int nact = min(p.trunc + 1, p.trunc + 2 - m);
+    const int nact = min(p.trunc + 1, p.trunc + 2 - min(m, p.mx - 1));
     int ntile[2];
     UNROLL for (int par = 0; par < 2; ++par) ntile[par] = (((nact + 1 - par) >> 1) + 15) >> 4;
     d4 acc[2][NTD];
     UNROLL for (int q = 0; q < 2; ++q) {
         UNROLL for (int t = 0; t < NTD; ++t) acc[q][t] = (d4){0.0, 0.0, 0.0, 0.0};
     }
-    const double *fw = fsm + w * wstride + (lane & 15);
-    for (int ks = 0; ks < p.js_dir; ++ks) {
-        const int j = 4 * ks + (lane >> 4);
-        const double south = fw[(p.il - 1 - j) * 16], north = fw[j * 16];
-        const double bv[2] = {south + north, south - north};
+    if (wvalid) {
+        // A fragments stream from L2 (they are shared by every field block): fetch k-step ks+1 while the matrix
+        // cores work on ks, otherwise every k-step starts with an exposed L2 round trip
+        const double *fw = fsm + w * wstride + (lane & 15);
+        const double *abase = p.pa_dir + ((long)(m * 2) * p.nt_dir) * p.js_dir * 64 + lane;   // [(m*2+par)*nt_dir + t][ks][64]
+        const long pstride = (long)p.nt_dir * p.js_dir * 64, tstride = (long)p.js_dir * 64;
+        double a_nxt[2][NTD];
         UNROLL for (int par = 0; par < 2; ++par) {
-            const double *asrc = p.pa_dir + (((long)(m * 2 + par) * p.nt_dir) * p.js_dir + ks) * 64 + lane;
-            UNROLL for (int t = 0; t < NTD; ++t) {
-                if (t < ntile[par])
-                    acc[par][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(asrc[(long)t * p.js_dir * 64], bv[par],
-                                                                       acc[par][t], 0, 0, 0);
-            }
+            UNROLL for (int t = 0; t < NTD; ++t) a_nxt[par][t] = t < ntile[par] ? abase[par * pstride + t * tstride] : 0.0;
         }
-    }
-    const int col = lane & 15, fld = b0 + (col >> 1), part = col & 1;
-    if (fld < nb) {
-        double *base = spec + 2 * ((long)fld * p.nx * p.mx + m) + part;
-        UNROLL for (int par = 0; par < 2; ++par) {
-            UNROLL for (int t = 0; t < NTD; ++t) {
-                UNROLL for (int rg = 0; rg < 4; ++rg) {
-                    const int n = 2 * (16 * t + (lane >> 4) + 4 * rg) + par;
-                    if (n < p.nx) base[2 * (long)n * p.mx] = acc[par][t][rg];
+        for (int ks = 0; ks < p.js_dir; ++ks) {
+            double a_cur[2][NTD];
+            UNROLL for (int par = 0; par < 2; ++par) {
+                UNROLL for (int t = 0; t < NTD; ++t) a_cur[par][t] = a_nxt[par][t];
+            }
+            const int kn = min(ks + 1, p.js_dir - 1);
+            UNROLL for (int par = 0; par < 2; ++par) {
+                UNROLL for (int t = 0; t < NTD; ++t)
+                    if (t < ntile[par]) a_nxt[par][t] = abase[par * pstride + t * tstride + kn * 64];
+            }
+            const int j = 4 * ks + (lane >> 4);
+            const double south = fw[(p.il - 1 - j) * 16], north = fw[j * 16];
+            const double bv[2] = {south + north, south - north};
+            UNROLL for (int par = 0; par < 2; ++par) {
+                UNROLL for (int t = 0; t < NTD; ++t) {
+                    if (t < ntile[par])
+                        acc[par][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[par][t], bv[par], acc[par][t], 0, 0, 0);
                 }
             }
         }
     }
+    // Output through LDS (see legendre_inv_kernel): image [n][field][18: 8 x (re, im) + pad], then one 128-byte
+    // piece of a spectral row per 8 lanes.  Inactive coefficients are written as the zeros they are.
+    __syncthreads();                                  // every wave is done with the Fourier image
+    const int col = lane & 15, part = col & 1;
+    if (wvalid) {
+        UNROLL for (int par = 0; par < 2; ++par) {
+            UNROLL for (int t = 0; t < NTD; ++t) {
+                UNROLL for (int rg = 0; rg < 4; ++rg) {
+                    const int n = 2 * (16 * t + (lane >> 4) + 4 * rg) + par;
+                    if (n < p.nx) fsm[(n * LEG_BT + (col >> 1)) * 18 + 2 * w + part] = acc[par][t][rg];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < p.nx * LEG_BT * LEG_MG; e += LEG_NT) {
+        const int mi = e & (LEG_MG - 1), fld = (e >> 3) & (LEG_BT - 1), n = e >> 6;
+        if (b0 + fld < nb && m0 + mi < p.mx)
+            *reinterpret_cast<double2 *>(spec + 2 * (((long)(b0 + fld) * p.nx + n) * p.mx + m0 + mi)) =
+                *reinterpret_cast<const double2 *>(fsm + (n * LEG_BT + fld) * 18 + 2 * mi);
+    }
+    }   // tile loop
+#undef LDIR_FETCH
 }
 
 // ------------------------------------------------------------------------------------------
@@ -770,11 +834,23 @@ __global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *_
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
+// grid limit of the persistent kernels: 3 blocks per CU (the FFT kernels' LDS footprint allows exactly that)
+static int fft_grid_limit()
+{
+    static int limit = 0;
+    if (!limit) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        limit = 3 * cus;
+    }
+    return limit;
+}
+
 hipError_t launch_legendre_inv(const DevPlan &p, int nb, const double *spec, double *four, hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
     const dim3 grid((nb + LEG_BT - 1) / LEG_BT, (p.mx + LEG_MG - 1) / LEG_MG);
-    const size_t lds = sizeof(double) * LEG_MG * (2 * 4 * p.ks_inv * 16 + 2);
+    const size_t lds = sizeof(double) * std::max(LEG_MG * (2 * 4 * p.ks_inv * 16 + 2), 32 * LEG_BT * 18);   // B image / output lines
     if (p.jt == 2) hipLaunchKernelGGL(legendre_inv_kernel<2>, grid, dim3(LEG_NT), lds, s, p, nb, spec, four);
     else if (p.jt == 3) {
         static bool attr_set = false;
@@ -792,8 +868,10 @@ hipError_t launch_legendre_inv(const DevPlan &p, int nb, const double *spec, dou
 hipError_t launch_legendre_dir(const DevPlan &p, int nb, const double *four, double *spec, hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
-    const dim3 grid((nb + LEG_BT - 1) / LEG_BT, (p.mx + LEG_MG - 1) / LEG_MG);
-    const size_t lds = sizeof(double) * LEG_MG * (p.il * 16 + 2);
+    if (p.il != (p.nt_dir == 3 ? 96 : 48)) return hipErrorInvalidValue;
+    const int ntiles = ((nb + LEG_BT - 1) / LEG_BT) * ((p.mx + LEG_MG - 1) / LEG_MG);
+    const size_t lds = sizeof(double) * std::max(LEG_MG * (p.il * 16 + 2), p.nx * LEG_BT * 18);   // Fourier image / output lines
+    const dim3 grid(std::min(ntiles, (int)(160 * 1024 / lds) * fft_grid_limit() / 3));              // persistent: resident blocks only
     if (p.nt_dir == 1) hipLaunchKernelGGL(legendre_dir_kernel<1>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
     else if (p.nt_dir == 3) {
         static bool attr_set = false;
@@ -806,18 +884,6 @@ hipError_t launch_legendre_dir(const DevPlan &p, int nb, const double *four, dou
         hipLaunchKernelGGL(legendre_dir_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
-}
-
-// persistent FFT blocks: as many as can be resident (LDS-limited: 3 per CU at ~50 KB per block)
-static int fft_grid_limit()
-{
-    static int limit = 0;
-    if (!limit) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        limit = 3 * cus;
-    }
-    return limit;
 }
 
 hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, const int *d_kcos, int kcos_all,
