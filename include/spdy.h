@@ -132,6 +132,23 @@ int spdy_implicit_terms_dev(spdy_plan *plan, double *divdt, double *tdt, double 
  * {dmp,dmpd,dmps,dmp1,dmp1d,dmp1s}; *d_ptr stays valid until the next spdy_implicit_init.     */
 int spdy_device_table(spdy_plan *plan, const char *name, const double **d_ptr);
 
+/* ---- HIP graphs: replaying a fixed sequence of device-resident calls --------------------------------
+ * A model step is the same sequence of small launches every time (tendencies.f90:89-107, :212-234,
+ * time_stepping.f90:56-121: ~90 inverse and ~70 direct transforms plus the spectral operators, 7 horizontal
+ * diffusions and implicit_terms at T30 L8).  At those batch sizes a launch costs as much as the kernel, so the
+ * sequence can be recorded once and replayed as one graph launch:
+ *     spdy_graph_begin(plan);  <any *_dev calls on this plan>;  spdy_graph_end(plan, &g);  spdy_graph_launch(g); ...
+ * Between begin and end nothing executes; the calls are captured from the plan's stream (which must not be the
+ * legacy default stream) with the pointer arguments they were given.  Host-pointer entry points, profiling and
+ * spdy_plan_synchronize are refused while a capture is open (SPDY_ERR_STATE).  spdy_graph_launch enqueues the
+ * whole sequence on the plan's stream.  (The reference has no counterpart: it calls the transforms one field
+ * at a time, spectral.f90:98-122.)                                                                          */
+typedef struct spdy_graph spdy_graph;
+int spdy_graph_begin(spdy_plan *plan);
+int spdy_graph_end(spdy_plan *plan, spdy_graph **graph);
+int spdy_graph_launch(spdy_graph *graph);
+int spdy_graph_destroy(spdy_graph *graph);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,5 +10,5 @@ The directory name contains a dot, so import it through the repo-root shim
 ``import speedy_f90_amd`` (speedy_f90_amd.py).
 """
 from ._lib import LIB_PATH, SpdyError, build, load  # noqa: F401
-from .spectral import RESOLUTIONS, Spectral  # noqa: F401
+from .spectral import RESOLUTIONS, Graph, Spectral, check  # noqa: F401
 from . import sharding  # noqa: F401

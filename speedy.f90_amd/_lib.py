@@ -53,6 +53,10 @@ SIGNATURES = {
     "spdy_implicit_terms": [c_void_p, c_void_p, c_void_p, c_void_p],
     "spdy_implicit_terms_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
     "spdy_device_table": [c_void_p, c_char_p, ctypes.POINTER(c_void_p)],
+    "spdy_graph_begin": [c_void_p],
+    "spdy_graph_end": [c_void_p, ctypes.POINTER(c_void_p)],
+    "spdy_graph_launch": [c_void_p],
+    "spdy_graph_destroy": [c_void_p],
 }
 
 

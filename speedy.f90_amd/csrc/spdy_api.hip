@@ -17,6 +17,12 @@
 using spdy::DevPlan;
 using spdy::HostTables;
 
+struct spdy_graph {
+    struct spdy_plan *plan = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 struct spdy_plan {
     HostTables tab;
     int max_batch = 0;
@@ -36,6 +42,7 @@ struct spdy_plan {
     int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
+    bool capturing = false;           // between spdy_graph_begin and spdy_graph_end
     struct Span { int kind; hipEvent_t t0, t1; };
     std::vector<Span> spans;
 };
@@ -230,11 +237,13 @@ int check_batch(const spdy_plan *p, int nb)
 
 int h2d(spdy_plan *p, double *dst, const double *src, size_t n)
 {
+    if (p->capturing) return fail(SPDY_ERR_STATE, "host-pointer entry points cannot be captured into a graph");
     if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
     return SPDY_OK;
 }
 int d2h(spdy_plan *p, double *dst, const double *src, size_t n)
 {
+    if (p->capturing) return fail(SPDY_ERR_STATE, "host-pointer entry points cannot be captured into a graph");
     if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     return SPDY_OK;
 }
@@ -255,6 +264,7 @@ int four_from_host(spdy_plan *p, const double *src, int nb)
 }
 int sync(spdy_plan *p)
 {
+    if (p->capturing) return fail(SPDY_ERR_STATE, "cannot synchronise while a graph capture is open");
     HIP_TRY(hipStreamSynchronize(p->stream));
     return SPDY_OK;
 }
@@ -275,7 +285,7 @@ bool use_fused(const spdy_plan *p, int nb)
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
-    if (!p->profiling) { HIP_TRY(launch()); return SPDY_OK; }
+    if (!p->profiling || p->capturing) { HIP_TRY(launch()); return SPDY_OK; }
     spdy_plan::Span sp{kind, nullptr, nullptr};
     HIP_TRY(hipEventCreate(&sp.t0));
     HIP_TRY(hipEventCreate(&sp.t1));
@@ -356,6 +366,7 @@ int spdy_plan_destroy(spdy_plan *p)
 int spdy_plan_set_stream(spdy_plan *p, void *hip_stream)
 {
     NEED_DEVICE(p);
+    if (p->capturing) return fail(SPDY_ERR_STATE, "cannot change the stream while a graph capture is open");
     p->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->own_stream;
     return SPDY_OK;
 }
@@ -385,6 +396,7 @@ int spdy_plan_get_profile(spdy_plan *p, double *ms, int *launches)
 {
     NEED_DEVICE(p);
     if (!ms || !launches) return fail(SPDY_ERR_ARG, "null output");
+    if (p->capturing) return fail(SPDY_ERR_STATE, "cannot read the profile while a graph capture is open");
     for (int k = 0; k < SPDY_K_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
     HIP_TRY(hipStreamSynchronize(p->stream));
     for (auto &sp : p->spans) {
@@ -744,6 +756,53 @@ int spdy_device_table(spdy_plan *p, const char *name, const double **d_ptr)
             return SPDY_OK;
         }
     return fail(SPDY_ERR_ARG, "no device table '%s'", name);
+}
+
+/* ---------------------------------------------------------------- HIP graphs */
+int spdy_graph_begin(spdy_plan *p)
+{
+    NEED_DEVICE(p);
+    if (p->capturing) return fail(SPDY_ERR_STATE, "a graph capture is already open on this plan");
+    if (!p->stream) return fail(SPDY_ERR_STATE, "graph capture needs a non-default stream (spdy_plan_set_stream)");
+    HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    p->capturing = true;
+    return SPDY_OK;
+}
+
+int spdy_graph_end(spdy_plan *p, spdy_graph **graph)
+{
+    NEED_DEVICE(p);
+    if (!graph) return fail(SPDY_ERR_ARG, "graph == NULL");
+    if (!p->capturing) return fail(SPDY_ERR_STATE, "no graph capture is open on this plan");
+    p->capturing = false;
+    spdy_graph *g = new spdy_graph;
+    g->plan = p;
+    hipError_t e = hipStreamEndCapture(p->stream, &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return fail(SPDY_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+    }
+    *graph = g;
+    return SPDY_OK;
+}
+
+int spdy_graph_launch(spdy_graph *g)
+{
+    if (!g || !g->exec) return fail(SPDY_ERR_ARG, "graph == NULL");
+    if (g->plan->capturing) return fail(SPDY_ERR_STATE, "cannot launch a graph while a capture is open");
+    HIP_TRY(hipGraphLaunch(g->exec, g->plan->stream));
+    return SPDY_OK;
+}
+
+int spdy_graph_destroy(spdy_graph *g)
+{
+    if (!g) return SPDY_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return SPDY_OK;
 }
 
 }  // extern "C"

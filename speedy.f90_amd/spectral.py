@@ -25,6 +25,46 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class Graph:
+    """A captured sequence of device-resident calls (spdy_graph_* in include/spdy.h)."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, handle
+
+    def launch(self):
+        check(self.lib.spdy_graph_launch(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.spdy_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _GraphCapture:
+    def __init__(self, sp):
+        self.sp, self.graph = sp, Graph(sp.lib, None)
+
+    def __enter__(self):
+        check(self.sp.lib.spdy_graph_begin(self.sp.h))
+        return self.graph
+
+    def __exit__(self, exc_type, exc, tb):
+        h = ctypes.c_void_p()
+        rc = self.sp.lib.spdy_graph_end(self.sp.h, ctypes.byref(h))
+        if exc_type is None:
+            check(rc)
+            self.graph.h = h
+        elif rc == 0:
+            self.sp.lib.spdy_graph_destroy(h)
+        return False
+
+
 class Spectral:
     """One transform plan = the module state `initialize_spectral` builds (spectral.f90:20)."""
 
@@ -201,6 +241,17 @@ class Spectral:
 
     def synchronize(self):
         check(self.lib.spdy_plan_synchronize(self.h))
+
+    def graph_capture(self):
+        """Context manager: record the ``*_dev`` calls made inside it (nothing runs) and return a
+        :class:`Graph` whose ``launch()`` replays them as one HIP graph launch on the plan's stream::
+
+            with sp.graph_capture() as g:
+                sp.spec_to_grid_dev(spec, grid); sp.grid_to_spec_dev(grid, spec2)
+            g.launch(); sp.synchronize()
+
+        The plan must be on its own stream (or another non-default one), not torch's legacy default stream."""
+        return _GraphCapture(self)
 
     @staticmethod
     def _dp(t):
