@@ -213,6 +213,7 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_inv_kernel
     static_assert(FFT_ROWS * PER_ROW % NT == 0, "whole pieces per thread");
     __shared__ double tile[FFT_ROWS * RS];
     __shared__ double tw[(TPR - 1) * 48];   // ido=48 twiddles: the index depends on the lane's column h -> LDS, not scalar loads
+    __shared__ double rowsc[FFT_ROWS];      // per-row output factor
     const int tid = threadIdx.x, r = tid & (FFT_ROWS - 1), h = tid / FFT_ROWS;
     const int ntiles = (nrows + FFT_ROWS - 1) / FFT_ROWS;
     for (int e = tid; e < (TPR - 1) * 48; e += NT) tw[e] = fftc<NF>().first[e];
@@ -314,23 +315,27 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_inv_kernel
     {
         double *rowp = tile + r * RS;
         UNROLL for (int t = 0; t < 48; ++t) rowp[TPR * t + h] = y[t];
+        if (h == 0) {                                  // this row's output factor: 1 (kcos == 1) or 1/cos(lat)
+            const int grow = (int)row0 + r, fld = grow / il, j = grow - fld * il;
+            int kc = 1;
+            if (r < nvalid) kc = d_kcos ? d_kcos[fld] : kcos_all;
+            rowsc[r] = kc == 1 ? 1.0 : cosgr[j];
+        }
     }
     __syncthreads();
 
-    // phase 4: coalesced store (+ optional 1/cos(lat) scaling, fourier.f90:47-51)
+    // phase 4: coalesced store (+ optional 1/cos(lat) scaling, fourier.f90:47-51; the factor of each row was put
+    // into LDS by one lane per row -- a 64-bit divide per 16-byte piece used to dominate this phase)
     {
         double2 *dst = reinterpret_cast<double2 *>(grid + row0 * NF);
         constexpr int per_row = NF / 2;
-        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
-            const int rr = e / per_row, c2 = e - rr * per_row;
+        int tl4 = tid;
+        asm volatile("" : "+v"(tl4));                  // per tile (no hoisting of the unrolled offsets into registers)
+        UNROLL for (int i = 0; i < FFT_ROWS * per_row / NT; ++i) {
+            const int e = tl4 + i * NT, rr = e / per_row, c2 = e - rr * per_row;
             if (rr < nvalid) {
-                const long grow = row0 + rr;
-                const int fld = (int)(grow / il), j = (int)(grow - (long)fld * il);
-                const int kc = d_kcos ? d_kcos[fld] : kcos_all;
-                const double sc = kc == 1 ? 1.0 : cosgr[j];
-                double2 v = make_double2(tile[rr * RS + 2 * c2], tile[rr * RS + 2 * c2 + 1]);
-                if (kc != 1) { v.x *= sc; v.y *= sc; }
-                dst[e] = v;
+                const double sc = rowsc[rr];
+                dst[e] = make_double2(tile[rr * RS + 2 * c2] * sc, tile[rr * RS + 2 * c2 + 1] * sc);
             }
         }
     }
@@ -357,18 +362,20 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel
     for (int e = tid; e < (TPR - 1) * 48; e += NT) tw[e] = c.first[e];
 
     // persistent over row tiles with a register prefetch of the next tile's grid rows (see fourier_inv_kernel)
+    // the first NEARLY pieces are fetched before the FFT (as many as fit next to its 192 registers), the rest after it
+    constexpr int NEARLY = NPRE / 2;
     double2 pre[NPRE];
-#define FDIR_FETCH(tile_)                                                                          \
+#define FDIR_FETCH(tile_, I0, I1)                                                                  \
     do {                                                                                           \
         const long r0_ = (long)(tile_) * FFT_ROWS;                                                 \
         const double2 *src_ = reinterpret_cast<const double2 *>(grid + r0_ * NF);                  \
         const long lim_ = ((long)nrows - r0_) * PER_ROW;                                           \
-        UNROLL for (int i = 0; i < NPRE; ++i) {                                                    \
+        UNROLL for (int i = (I0); i < (I1); ++i) {                                                 \
             const int e_ = tid + i * NT;                                                           \
             pre[i] = e_ < lim_ ? src_[e_] : make_double2(0.0, 0.0);                                \
         }                                                                                          \
     } while (0)
-    if ((int)blockIdx.x < ntiles) FDIR_FETCH(blockIdx.x);
+    if ((int)blockIdx.x < ntiles) FDIR_FETCH(blockIdx.x, 0, NPRE);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long row0 = (long)t * FFT_ROWS;
     const int nvalid = (int)min((long)FFT_ROWS, (long)nrows - row0);
@@ -381,12 +388,13 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel
         const int e = tl + i * NT, rr = e / PER_ROW, c2 = e - rr * PER_ROW;
         double2 v = pre[i];
         if (gscale) {
-            const double sc = gscale[(int)((row0 + rr) % il)];
+            const double sc = gscale[((int)row0 + rr) % il];
             v.x *= sc; v.y *= sc;
         }
         tile[rr * RS + 2 * c2] = v.x;
         tile[rr * RS + 2 * c2 + 1] = v.y;
     }
+    if (t + (int)gridDim.x < ntiles) FDIR_FETCH(t + gridDim.x, 0, NEARLY);   // in flight during the FFT
     __syncthreads();
 
     // phase 2: decimated samples TPR*t + h -> 48-point forward sub-transform
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel
         double *rowp = tile + r * RS + 48 * h;
         UNROLL for (int i = 0; i < 48; ++i) rowp[i] = y[i];
     }
-    if (t + (int)gridDim.x < ntiles) FDIR_FETCH(t + gridDim.x);   // the FFT registers are dead: next tile in flight during phases 3-4
+    if (t + (int)gridDim.x < ntiles) FDIR_FETCH(t + gridDim.x, NEARLY, NPRE);   // the FFT registers are dead: the rest of the next tile
     __syncthreads();
 
     // phase 3: the ido=48 stage, in place.  Butterflies p and 46-p touch the same 4*TPR slots,
@@ -474,9 +482,11 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel
     // phase 4: scale by float32(1/N), pack (a0, 0, re1, im1, ...) and store coalesced
     {
         double2 *dst = reinterpret_cast<double2 *>(four + row0 * fs);
-        const int per_row = fs / 2;
-        for (int e = tid; e < FFT_ROWS * per_row; e += NT) {
-            const int rr = e / per_row, c2 = e - rr * per_row;
+        constexpr int per_row = (TWO_MX + 15) / 16 * 8;   // = fs / 2 (launcher checks)
+        int tl4 = tid;
+        asm volatile("" : "+v"(tl4));                  // per tile (no hoisting of the unrolled offsets into registers)
+        UNROLL for (int i = 0; i < FFT_ROWS * per_row / NT; ++i) {
+            const int e = tl4 + i * NT, rr = e / per_row, c2 = e - rr * per_row;
             if (rr < nvalid) {
                 double2 v = make_double2(0.0, 0.0);
                 const double *z = tile + rr * RS;
@@ -909,6 +919,7 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
     if (nb <= 0) return hipSuccess;
     const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
     const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, fft_grid_limit());
+    if (p.fs != (2 * p.mx + 15) / 16 * 16) return hipErrorInvalidValue;
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_dir_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, grid, gscale, four,
                            nrows, p.il, p.fs);
