@@ -588,9 +588,8 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
     RC(check_batch(p, nb));
     const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
     if (use_fused(p, nb)) {
-        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, p->stage_c, p->num_cu * p->wg_per_cu, p->stream));
-        KERNEL(spdy::launch_g2s_fused(p->dev, nb, vg, sc, p->stage_d, p->num_cu * p->wg_per_cu, p->stream));
-        KERNEL(spdy::launch_vds(p->dev, nb, p->stage_c, p->stage_d, vorm, divm, p->stream));
+        // one pass: the pair (ug[i], vg[i]) is one tile, vds is applied to the two spectra while they are in LDS
+        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
         return SPDY_OK;
     }
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, ug, sc, p->four, p->stream));

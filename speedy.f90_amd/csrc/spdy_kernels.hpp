@@ -46,8 +46,10 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
 // Fused persistent T30 kernels (whole transform in one pass through LDS; at most max_wg workgroups)
 hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid,
                             int max_wg, hipStream_t s);
+// grid2 / spec2 non-null: vdspec in one pass -- tile i is the pair (grid[i], grid2[i]) scaled by gscale, the
+// outputs are vds of the pair's spectra: vorticity -> spec, divergence -> spec2 (nb pairs)
 hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg,
-                            hipStream_t s);
+                            hipStream_t s, const double *grid2 = nullptr, double *spec2 = nullptr);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };
 hipError_t launch_scale_op(const DevPlan &p, int op, int nb, const double *in, double *out, hipStream_t s);
