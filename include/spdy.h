@@ -132,6 +132,17 @@ int spdy_implicit_terms_dev(spdy_plan *plan, double *divdt, double *tdt, double 
  * {dmp,dmpd,dmps,dmp1,dmp1d,dmp1s}; *d_ptr stays valid until the next spdy_implicit_init.     */
 int spdy_device_table(spdy_plan *plan, const char *name, const double **d_ptr);
 
+/* ---- fused operator + transform sequences (device-resident; extensions of the reference interface) ------
+ * The reference's callers always follow uvspec by two spec_to_grid(.,2) (tendencies.f90:98-100, physics.f90:96-98)
+ * and grad by two spec_to_grid(.,2) (tendencies.f90:121-123).  These entry points do each sequence in one pass:
+ * the operator is applied while the spectra are staged for the inverse transform, so the intermediate spectra
+ * never exist in memory.  Results equal spdy_uvspec_dev / spdy_grad_dev followed by spdy_spec_to_grid_dev.
+ *   spdy_uvspec_to_grid_dev : (vor, div)[nb] -> ug, vg [nb] grids     (spectral.f90:173-196 + :98-110)
+ *   spdy_grad_to_grid_dev   : psi[nb]        -> gx, gy [nb] grids     (spectral.f90:124-144 + :98-110)          */
+int spdy_uvspec_to_grid_dev(spdy_plan *plan, int nb, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
+                            int kcos);
+int spdy_grad_to_grid_dev(spdy_plan *plan, int nb, const double *d_psi, double *d_gx, double *d_gy, int kcos);
+
 /* ---- HIP graphs: replaying a fixed sequence of device-resident calls --------------------------------
  * A model step is the same sequence of small launches every time (tendencies.f90:89-107, :212-234,
  * time_stepping.f90:56-121: ~90 inverse and ~70 direct transforms plus the spectral operators, 7 horizontal

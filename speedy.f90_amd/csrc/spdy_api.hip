@@ -580,6 +580,33 @@ int spdy_uvspec_dev(spdy_plan *p, int nb, const double *vor, const double *dv, d
     KERNEL(spdy::launch_uvspec(p->dev, nb, vor, dv, u, v, p->stream));
     return SPDY_OK;
 }
+/* uvspec / grad followed by the two inverse transforms their callers always do, in one pass where the fused
+ * kernels exist; otherwise the operator kernel into stage_c/stage_d and two ordinary transforms.             */
+static int derived_to_grid(spdy_plan *p, int nb, int mode, const double *in0, const double *in1, double *g0, double *g1, int kcos)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!in0 || (mode == 1 && !in1) || !g0 || !g1)) return fail(SPDY_ERR_ARG, "null device pointer");
+    if (kcos != 1 && kcos != 2) return fail(SPDY_ERR_ARG, "kcos must be 1 or 2");
+    if (use_fused(p, nb))
+        return timed(p, SPDY_K_S2G_FUSED, [&] {
+            return spdy::launch_s2g_fused(p->dev, nb, in0, nullptr, kcos, g0, p->num_cu * p->wg_per_cu, p->stream, mode, in1, g1);
+        });
+    if (mode == 1) KERNEL(spdy::launch_uvspec(p->dev, nb, in0, in1, p->stage_c, p->stage_d, p->stream));
+    else KERNEL(spdy::launch_grad(p->dev, nb, in0, p->stage_c, p->stage_d, p->stream));
+    RC(spdy_spec_to_grid_dev(p, nb, p->stage_c, nullptr, kcos, g0));
+    RC(spdy_spec_to_grid_dev(p, nb, p->stage_d, nullptr, kcos, g1));
+    return SPDY_OK;
+}
+int spdy_uvspec_to_grid_dev(spdy_plan *p, int nb, const double *vor, const double *dv, double *ug, double *vg, int kcos)
+{
+    return derived_to_grid(p, nb, 1, vor, dv, ug, vg, kcos);
+}
+int spdy_grad_to_grid_dev(spdy_plan *p, int nb, const double *psi, double *gx, double *gy, int kcos)
+{
+    return derived_to_grid(p, nb, 2, psi, nullptr, gx, gy, kcos);
+}
+
 /* vdspec: scale on load, two direct transforms, then vds.  Uses stage_c/stage_d as the two
  * intermediate spectra, so ug/vg/vorm/divm may be the caller's own device buffers.            */
 int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos)

@@ -44,8 +44,11 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
                               hipStream_t s);
 
 // Fused persistent T30 kernels (whole transform in one pass through LDS; at most max_wg workgroups)
+// mode 0: plain.  mode 1: uvspec fused -- tile i = (vor[i], div[i]) = (spec, spec2) -> (ug, vg) = (grid, grid2).
+// mode 2: grad fused -- tile i = psi[i] = spec -> (d/dx, d/dy) = (grid, grid2).  In modes 1/2 nb counts tiles and
+// kcos_all applies to both outputs.
 hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid,
-                            int max_wg, hipStream_t s);
+                            int max_wg, hipStream_t s, int mode = 0, const double *spec2 = nullptr, double *grid2 = nullptr);
 // grid2 / spec2 non-null: vdspec in one pass -- tile i is the pair (grid[i], grid2[i]) scaled by gscale, the
 // outputs are vds of the pair's spectra: vorticity -> spec, divergence -> spec2 (nb pairs)
 hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg,

@@ -273,6 +273,14 @@ class Spectral:
     def vdspec_dev(self, ug, vg, vor, div, kcos=2):
         check(self.lib.spdy_vdspec_dev(self.h, ug.shape[0], self._dp(ug), self._dp(vg), self._dp(vor), self._dp(div), int(kcos)))
 
+    def uvspec_to_grid_dev(self, vor, div, ug, vg, kcos=2):
+        """uvspec followed by spec_to_grid(., kcos) of both results (tendencies.f90:98-100), one pass at T30."""
+        check(self.lib.spdy_uvspec_to_grid_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(ug), self._dp(vg), int(kcos)))
+
+    def grad_to_grid_dev(self, psi, gx, gy, kcos=2):
+        """grad followed by spec_to_grid(., kcos) of both results (tendencies.f90:121-123), one pass at T30."""
+        check(self.lib.spdy_grad_to_grid_dev(self.h, psi.shape[0], self._dp(psi), self._dp(gx), self._dp(gy), int(kcos)))
+
     def implicit_terms_dev(self, divdt, tdt, psdt):
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
 

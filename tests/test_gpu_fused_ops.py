@@ -1,0 +1,74 @@
+"""Operator + transform sequences done in one pass (include/spdy.h: spdy_uvspec_to_grid_dev, spdy_grad_to_grid_dev,
+and vdspec, which is one kernel at T30): against the oracle's own sequence of reference calls
+(uvspec / grad then spec_to_grid, spectral.f90:98-227) and against the library's unfused composition."""
+import numpy as np
+import pytest
+
+import synth
+from conftest import TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def ok(a, b, tol=TOL):
+    assert a.shape == b.shape
+    assert synth.relerr(a, b) <= tol, synth.relerr(a, b)
+
+
+@pytest.mark.parametrize("res,nb", [("t30", 1), ("t30", 24), ("t30", 257), ("t63", 5)])
+@pytest.mark.parametrize("kcos", [2, 1])
+def test_uvspec_and_grad_to_grid(res, nb, kcos, oracle_factory):
+    import torch
+    import speedy_f90_amd as s
+    o = oracle_factory(res)
+    sp = s.Spectral(res, kx=8, max_batch=max(nb, 8), device=0)
+    sp.use_torch_stream()
+    S = synth.spectra(2 * nb, sp.trunc, first=700, full_rows=True)     # row nx populated: uvspec must not care
+    vor, div = torch.from_numpy(S[:nb]).cuda(), torch.from_numpy(S[nb:]).cuda()
+    shape = (nb, sp.il, sp.ix)
+    ug, vg, gx, gy = (torch.full(shape, np.nan, dtype=torch.float64, device="cuda") for _ in range(4))
+    sp.uvspec_to_grid_dev(vor, div, ug, vg, kcos)
+    sp.grad_to_grid_dev(vor, gx, gy, kcos)
+    # the unfused composition through the same library
+    u, v, dx, dy = (torch.zeros_like(vor) for _ in range(4))
+    sp.uvspec_dev(vor, div, u, v)
+    check = __import__("speedy_f90_amd").check
+    check(sp.lib.spdy_grad_dev(sp.h, nb, sp._dp(vor), sp._dp(dx), sp._dp(dy)))
+    ref = [torch.zeros(shape, dtype=torch.float64, device="cuda") for _ in range(4)]
+    for src, dst in zip((u, v, dx, dy), ref):
+        sp.spec_to_grid_dev(src, dst, kcos=kcos)
+    torch.cuda.synchronize()
+    for got, want in zip((ug, vg, gx, gy), ref):
+        ok(got.cpu().numpy(), want.cpu().numpy(), 1e-13)
+    # the reference's own call sequence on a sample of the batch
+    for b in sorted({0, nb // 2, nb - 1}):
+        ru, rv = o.uvspec(S[b], S[nb + b])
+        ok(ug[b].cpu().numpy(), o.spec_to_grid(ru, kcos)); ok(vg[b].cpu().numpy(), o.spec_to_grid(rv, kcos))
+        rdx, rdy = o.grad(S[b])
+        ok(gx[b].cpu().numpy(), o.spec_to_grid(rdx, kcos)); ok(gy[b].cpu().numpy(), o.spec_to_grid(rdy, kcos))
+    sp.close()
+
+
+@pytest.mark.parametrize("nb", [1, 3, 48, 300])
+@pytest.mark.parametrize("kcos", [2, 1])
+def test_vdspec_one_pass(nb, kcos, oracle_factory):
+    import torch
+    import speedy_f90_amd as s
+    o = oracle_factory("t30")
+    sp = s.Spectral("t30", kx=8, max_batch=max(nb, 8), device=0)
+    sp.use_torch_stream()
+    G = synth.grids(2 * nb, sp.ix, sp.il, first=900)
+    ug, vg = torch.from_numpy(G[:nb]).cuda(), torch.from_numpy(G[nb:]).cuda()
+    outs = {}
+    for fused in (1, 0):                                   # one kernel / five kernels
+        sp.set_fused(fused)
+        vor = torch.full((nb, sp.nx, sp.mx), np.nan, dtype=torch.complex128, device="cuda")
+        div = torch.full_like(vor, np.nan)
+        sp.vdspec_dev(ug, vg, vor, div, kcos)
+        torch.cuda.synchronize()
+        outs[fused] = (vor.cpu().numpy(), div.cpu().numpy())
+    ok(outs[1][0], outs[0][0], 1e-13); ok(outs[1][1], outs[0][1], 1e-13)
+    for b in sorted({0, nb // 2, nb - 1}):
+        rvor, rdiv = o.vdspec(G[b], G[nb + b], kcos)
+        ok(outs[1][0][b], rvor); ok(outs[1][1][b], rdiv)
+    sp.close()

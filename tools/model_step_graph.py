@@ -30,16 +30,29 @@ out = [torch.zeros_like(f) for f in fld]
 psdt = torch.from_numpy(synth.spectra(1, sp.trunc, first=300)[0]).to(dev)
 
 
-def step():
-    sp.uvspec_dev(S[:kx], S[kx:2 * kx], u[:kx], v[:kx])
-    sp.uvspec_dev(S[2 * kx:3 * kx], S[3 * kx:4 * kx], u[kx:], v[kx:])
-    sp.spec_to_grid_dev(S, G, kcos=1)
-    sp.vdspec_dev(ug, vg, vor, div, 2)
+ugr, vgr = torch.zeros((2 * kx, sp.il, sp.ix), dtype=f64, device=dev), torch.zeros((2 * kx, sp.il, sp.ix), dtype=f64, device=dev)
+names = [("dmp", "dmp1"), ("dmpd", "dmp1d"), ("dmp", "dmp1"), ("dmp", "dmp1"), ("dmps", "dmp1s"), ("dmps", "dmp1s"), ("dmpd", "dmp1d")]
+
+
+def tail():
     sp.grid_to_spec_dev(G[:25], S2)
-    names = [("dmp", "dmp1"), ("dmpd", "dmp1d"), ("dmp", "dmp1"), ("dmp", "dmp1"), ("dmps", "dmp1s"), ("dmps", "dmp1s"), ("dmpd", "dmp1d")]
     for i, (a, b) in enumerate(names):
         sp.hdiff_dev(fld[i], fdt[i], a, b, out[i])
     sp.implicit_terms_dev(out[1], out[0], psdt)
+
+
+def step_calls():          # the reference's call sequence, batched: uvspec, then all 91 inverse transforms, vdspec, ...
+    sp.uvspec_dev(S[:2 * kx], S[2 * kx:4 * kx], u, v)
+    sp.spec_to_grid_dev(S, G, kcos=1)
+    sp.vdspec_dev(ug, vg, vor, div, 2)
+    tail()
+
+
+def step_fused():          # uvspec folded into its 32 inverse transforms; the other 59 as one batch
+    sp.uvspec_to_grid_dev(S[:2 * kx], S[2 * kx:4 * kx], ugr, vgr, 2)
+    sp.spec_to_grid_dev(S[:59], G[:59], kcos=1)
+    sp.vdspec_dev(ug, vg, vor, div, 2)
+    tail()
 
 
 def timeit(fn, n=200):
@@ -53,13 +66,14 @@ def timeit(fn, n=200):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-eager = timeit(step)
-with sp.graph_capture() as g:
-    step()
-graph = timeit(g.launch)
-print("T30 L8 spectral-side step: 91 inverse + 73 direct transforms, uvspec x2, vds, 7 hdiff, implicit_terms")
-print("  eager launches : %8.1f us per step" % eager)
-print("  one HIP graph  : %8.1f us per step" % graph)
+print("T30 L8 spectral-side step: 91 inverse + 73 direct transforms, uvspec, vds, 7 hdiff, implicit_terms")
+for label, fn in (("operator kernels + batched transforms", step_calls), ("uvspec folded into the inverse transform", step_fused)):
+    eager = timeit(fn)
+    with sp.graph_capture() as g:
+        fn()
+    graph = timeit(g.launch)
+    print("  %-42s eager %7.1f us   one HIP graph %7.1f us per step" % (label, eager, graph))
+    g.close()
 try:
     from oracle.pyoracle import Reference
     ref = Reference("t30")

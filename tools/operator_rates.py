@@ -52,3 +52,22 @@ if res == "t30":
     us = e0.elapsed_time(e1) / 20 * 1e3
     byts = half * 2 * (sp.il * sp.ix * 8 + arr)
     print("%-20s %8.1f us  %7.1f GB/s (%d (u,v) pairs: 2 grids in, vor + div out)" % ("vdspec (one pass)", us, byts / us / 1e3, half))
+    U1, U2 = (torch.zeros((half, sp.il, sp.ix), dtype=torch.float64, device=dev) for _ in range(2))
+    def timed(name, fn, byts):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        print("%-34s %8.1f us  %7.1f GB/s" % (name, us, byts / us / 1e3))
+    io = half * 2 * (sp.il * sp.ix * 8 + arr)
+    timed("uvspec_to_grid (one pass)", lambda: sp.uvspec_to_grid_dev(A[:half], B[:half], U1, U2, 2), io)
+    def two_step():
+        sp.uvspec_dev(A[:half], B[:half], C[:half], D[:half])
+        sp.spec_to_grid_dev(C[:half], U1, kcos=2); sp.spec_to_grid_dev(D[:half], U2, kcos=2)
+    timed("uvspec + 2 x spec_to_grid", two_step, io)
+    timed("grad_to_grid (one pass)", lambda: sp.grad_to_grid_dev(A[:half], U1, U2, 2), half * (2 * sp.il * sp.ix * 8 + arr))
