@@ -164,6 +164,27 @@ def main():
     prof = sp.get_profile()
     sp.set_profiling(False)
 
+    # N > 1 only, outside the timed region and best-effort: the one exchange a level-sharded model step needs --
+    # all-gather of the implicit solve's inputs over RCCL -- timed on its own so the scaling of the
+    # transform metric can be read "with and without the gather"
+    gather_ms = None
+    if dist and args.res == "t30":
+        try:
+            lo, hi = s.sharding.shard_range(sp.kx, rank, world)
+            loc = torch.zeros((hi - lo, sp.nx, sp.mx), dtype=torch.complex128, device=dev)
+            for _ in range(5):
+                s.sharding.allgather_levels(loc, sp.kx); s.sharding.allgather_levels(loc, sp.kx)
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                s.sharding.allgather_levels(loc, sp.kx); s.sharding.allgather_levels(loc, sp.kx)   # divdt and tdt
+            torch.cuda.synchronize()
+            gather_ms = s.sharding.max_over_ranks((time.perf_counter() - t0) / 50 * 1e3, dev)
+        except Exception as e:  # never let the optional measurement break the bench line
+            gather_ms = None
+            if rank == 0:
+                print("implicit all-gather timing skipped: %s" % e, file=sys.stderr)
+
     if rank == 0:
         ab = algorithmic_bytes(sp)
         value = world * nb * args.steps / elapsed
@@ -196,6 +217,8 @@ def main():
                          "launch_ms": dom_ms, "bytes_per_launch": ab[dom] * nb,
                          "all_kernels_ms": kinds},
         }
+        if world > 1:
+            res["implicit_allgather_ms"] = gather_ms   # 2 x all-gather of [kx, nx, mx] complex level slabs, per model step
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.res)
             res["gpu_over_cpu_core"] = value / res["cpu_baseline"]["value"]
