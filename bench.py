@@ -93,8 +93,8 @@ def cpu_baseline_all_cores(res, fields=64, target_s=4.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", default="t30", choices=["t30", "t63"])
     ap.add_argument("--batch", type=int, default=0, help="fields per GPU (default 6144 at T30, 1536 at T63)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +120,7 @@ def main():
 
     nb = args.batch or (6144 if args.res == "t30" else 1536)
     sp = s.Spectral(args.res, kx=8, max_batch=nb, device=local)
-    sp.use_torch_stream()
+    # the plan keeps its own (non-default) stream; torch.cuda.synchronize() below covers every stream of the device
     sp.set_fused(args.fused)
 
     # synthetic white-noise grids: 64 seeded templates tiled and rescaled per field so
@@ -137,6 +137,7 @@ def main():
         sp.grid_to_spec_dev(grid, spec)
         sp.spec_to_grid_dev(spec, out, kcos=1)
 
+    torch.cuda.synchronize()             # the inputs were produced on torch's stream; the plan runs on its own
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
