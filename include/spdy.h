@@ -114,6 +114,8 @@ int spdy_trunct_dev(spdy_plan *plan, int nb, double *inout);
 int spdy_grad_dev(spdy_plan *plan, int nb, const double *psi, double *psdx, double *psdy);
 int spdy_vds_dev(spdy_plan *plan, int nb, const double *ucosm, const double *vcosm, double *vorm, double *divm);
 int spdy_uvspec_dev(spdy_plan *plan, int nb, const double *vorm, const double *divm, double *ucosm, double *vcosm);
+/* device-pointer operators: outputs must not overlap inputs (except spdy_trunct_dev, which is in place);
+ * vdspec at T30 is one kernel and writes its outputs while other inputs are still being read */
 int spdy_vdspec_dev(spdy_plan *plan, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos);
 
 /* ---- spectral-space tail ------------------------------------------------------------------
@@ -142,6 +144,9 @@ int spdy_device_table(spdy_plan *plan, const char *name, const double **d_ptr);
 int spdy_uvspec_to_grid_dev(spdy_plan *plan, int nb, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
                             int kcos);
 int spdy_grad_to_grid_dev(spdy_plan *plan, int nb, const double *d_psi, double *d_gx, double *d_gy, int kcos);
+/* the same with host pointers (one H2D + one D2H round trip for a whole level stack) */
+int spdy_uvspec_to_grid(spdy_plan *plan, int nb, const double *vor, const double *div, double *ug, double *vg, int kcos);
+int spdy_grad_to_grid(spdy_plan *plan, int nb, const double *psi, double *gx, double *gy, int kcos);
 
 /* ---- HIP graphs: replaying a fixed sequence of device-resident calls --------------------------------
  * A model step is the same sequence of small launches every time (tendencies.f90:89-107, :212-234,

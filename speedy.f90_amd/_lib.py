@@ -55,6 +55,8 @@ SIGNATURES = {
     "spdy_device_table": [c_void_p, c_char_p, ctypes.POINTER(c_void_p)],
     "spdy_uvspec_to_grid_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "spdy_grad_to_grid_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
+    "spdy_uvspec_to_grid": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "spdy_grad_to_grid": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
     "spdy_graph_begin": [c_void_p],
     "spdy_graph_end": [c_void_p, ctypes.POINTER(c_void_p)],
     "spdy_graph_launch": [c_void_p],

@@ -607,12 +607,44 @@ int spdy_grad_to_grid_dev(spdy_plan *p, int nb, const double *psi, double *gx, d
     return derived_to_grid(p, nb, 2, psi, nullptr, gx, gy, kcos);
 }
 
+/* host-pointer forms (level stacks of the Fortran host): inputs to stage_a/b, grids come back from stage_c/d --
+ * or, where the multi-kernel path keeps its intermediate spectra in stage_c/d, from stage_a/b               */
+static int derived_to_grid_host(spdy_plan *p, int nb, int mode, const double *in0, const double *in1, double *g0, double *g1, int kcos)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nb));
+    if (nb && (!in0 || (mode == 1 && !in1) || !g0 || !g1)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(h2d(p, p->stage_a, in0, nb * spec_elems(p)));
+    if (mode == 1) RC(h2d(p, p->stage_b, in1, nb * spec_elems(p)));
+    const bool one_pass = use_fused(p, nb);
+    double *o0 = one_pass ? p->stage_c : p->stage_a, *o1 = one_pass ? p->stage_d : p->stage_b;
+    if (one_pass) RC(derived_to_grid(p, nb, mode, p->stage_a, p->stage_b, o0, o1, kcos));
+    else {
+        if (mode == 1) KERNEL(spdy::launch_uvspec(p->dev, nb, p->stage_a, p->stage_b, p->stage_c, p->stage_d, p->stream));
+        else KERNEL(spdy::launch_grad(p->dev, nb, p->stage_a, p->stage_c, p->stage_d, p->stream));
+        RC(spdy_spec_to_grid_dev(p, nb, p->stage_c, nullptr, kcos, o0));
+        RC(spdy_spec_to_grid_dev(p, nb, p->stage_d, nullptr, kcos, o1));
+    }
+    RC(d2h(p, g0, o0, nb * grid_elems(p)));
+    RC(d2h(p, g1, o1, nb * grid_elems(p)));
+    return sync(p);
+}
+int spdy_uvspec_to_grid(spdy_plan *p, int nb, const double *vor, const double *dv, double *ug, double *vg, int kcos)
+{
+    return derived_to_grid_host(p, nb, 1, vor, dv, ug, vg, kcos);
+}
+int spdy_grad_to_grid(spdy_plan *p, int nb, const double *psi, double *gx, double *gy, int kcos)
+{
+    return derived_to_grid_host(p, nb, 2, psi, nullptr, gx, gy, kcos);
+}
+
 /* vdspec: scale on load, two direct transforms, then vds.  Uses stage_c/stage_d as the two
  * intermediate spectra, so ug/vg/vorm/divm may be the caller's own device buffers.            */
 int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos)
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    if (nb && (!ug || !vg || !vorm || !divm)) return fail(SPDY_ERR_ARG, "null device pointer");
     const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
     if (use_fused(p, nb)) {
         // one pass: the pair (ug[i], vg[i]) is one tile, vds is applied to the two spectra while they are in LDS
@@ -693,11 +725,14 @@ int spdy_vdspec(spdy_plan *p, int nb, const double *ug, const double *vg, double
     if (nb && (!ug || !vg || !vorm || !divm)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, ug, nb * grid_elems(p)));
     RC(h2d(p, p->stage_b, vg, nb * grid_elems(p)));
-    // outputs land in the tails of stage_a/b only after both grids are consumed: use the Fourier
-    // workspace-independent spectra buffers stage_c/d inside, then vds writes into stage_a/b.
-    RC(spdy_vdspec_dev(p, nb, p->stage_a, p->stage_b, p->stage_a, p->stage_b, kcos));
-    RC(d2h(p, vorm, p->stage_a, nb * spec_elems(p)));
-    RC(d2h(p, divm, p->stage_b, nb * spec_elems(p)));
+    // The one-pass kernel writes vorticity/divergence while other workgroups still read grids: its outputs must
+    // not alias its inputs.  The multi-kernel path keeps its intermediate spectra in stage_c/d and lets vds write
+    // over the (by then consumed) grids in stage_a/b.
+    const bool one_pass = use_fused(p, nb);
+    double *o1 = one_pass ? p->stage_c : p->stage_a, *o2 = one_pass ? p->stage_d : p->stage_b;
+    RC(spdy_vdspec_dev(p, nb, p->stage_a, p->stage_b, o1, o2, kcos));
+    RC(d2h(p, vorm, o1, nb * spec_elems(p)));
+    RC(d2h(p, divm, o2, nb * spec_elems(p)));
     return sync(p);
 }
 

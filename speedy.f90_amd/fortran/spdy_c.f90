@@ -117,6 +117,22 @@ module spdy_c
             complex(c_double_complex), intent(out) :: vorm(*), divm(*)
             integer(c_int) :: rc
         end function
+        function spdy_uvspec_to_grid(plan, nb, vorm, divm, ug, vg, kcos) bind(C, name="spdy_uvspec_to_grid") result(rc)
+            import :: c_ptr, c_int, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb, kcos
+            complex(c_double_complex), intent(in) :: vorm(*), divm(*)
+            real(c_double), intent(out) :: ug(*), vg(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_grad_to_grid(plan, nb, psi, gx, gy, kcos) bind(C, name="spdy_grad_to_grid") result(rc)
+            import :: c_ptr, c_int, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb, kcos
+            complex(c_double_complex), intent(in) :: psi(*)
+            real(c_double), intent(out) :: gx(*), gy(*)
+            integer(c_int) :: rc
+        end function
         function spdy_hdiff(plan, nlev, field, fdt_in, dmp, dmp1, fdt_out) bind(C, name="spdy_hdiff") result(rc)
             import :: c_int, c_ptr, c_double, c_double_complex
             type(c_ptr), value :: plan

@@ -26,6 +26,7 @@ module spectral
     public grad, vds, uvspec, vdspec, trunct
     ! extensions (not in the reference)
     public spec_to_grid_levels, grid_to_spec_levels, finalize_spectral, spectral_plan
+    public uvspec_to_grid_levels, grad_to_grid_levels, vdspec_levels
 
     real(p), dimension(mx,nx) :: el2            !! l(l+1)/a^2, public in the reference (spectral.f90:8)
     type(c_ptr) :: spectral_plan = c_null_ptr   !! opaque spdy_plan*; replaces the private tables
@@ -129,5 +130,30 @@ contains
         real(p), intent(in) :: vorg(ix,il,nlev)
         complex(p), intent(out) :: vorm(mx,nx,nlev)
         call spdy_check(spdy_grid_to_spec_batch(spectral_plan, int(nlev, c_int), vorg, vorm), 'grid_to_spec_levels')
+    end subroutine
+
+    !> Extension: the loop body of tendencies.f90:98-100 for a whole level stack in one call --
+    !  uvspec(vorm(:,:,k), divm(:,:,k), u, v); ug(:,:,k) = spec_to_grid(u, 2); vg(:,:,k) = spec_to_grid(v, 2)
+    subroutine uvspec_to_grid_levels(nlev, vorm, divm, ug, vg)
+        integer, intent(in) :: nlev
+        complex(p), intent(in) :: vorm(mx,nx,nlev), divm(mx,nx,nlev)
+        real(p), intent(out) :: ug(ix,il,nlev), vg(ix,il,nlev)
+        call spdy_check(spdy_uvspec_to_grid(spectral_plan, int(nlev, c_int), vorm, divm, ug, vg, 2_c_int), 'uvspec_to_grid_levels')
+    end subroutine
+
+    !> Extension: grad(psi(:,:,k), dx, dy) followed by spec_to_grid(dx, 2), spec_to_grid(dy, 2) (tendencies.f90:121-123)
+    subroutine grad_to_grid_levels(nlev, psi, gx, gy)
+        integer, intent(in) :: nlev
+        complex(p), intent(in) :: psi(mx,nx,nlev)
+        real(p), intent(out) :: gx(ix,il,nlev), gy(ix,il,nlev)
+        call spdy_check(spdy_grad_to_grid(spectral_plan, int(nlev, c_int), psi, gx, gy, 2_c_int), 'grad_to_grid_levels')
+    end subroutine
+
+    !> Extension: vdspec for a whole level stack (tendencies.f90:216-232)
+    subroutine vdspec_levels(nlev, ug, vg, vorm, divm, kcos)
+        integer, intent(in) :: nlev, kcos
+        real(p), intent(in) :: ug(ix,il,nlev), vg(ix,il,nlev)
+        complex(p), intent(out) :: vorm(mx,nx,nlev), divm(mx,nx,nlev)
+        call spdy_check(spdy_vdspec(spectral_plan, int(nlev, c_int), ug, vg, vorm, divm, int(kcos, c_int)), 'vdspec_levels')
     end subroutine
 end module

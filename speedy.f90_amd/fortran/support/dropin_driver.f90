@@ -9,7 +9,8 @@ program dropin_driver
     implicit none
     complex(p) :: s(mx,nx,2), so(mx,nx), u(mx,nx), v(mx,nx), vor(mx,nx), div(mx,nx), dx(mx,nx), dy(mx,nx)
     complex(p) :: sk(mx,nx,kx), tk(mx,nx,kx), ps(mx,nx), hk(mx,nx,kx), slev(mx,nx,kx)
-    real(p) :: g(ix,il,2), go(ix,il), dmp(mx,nx), dmp1(mx,nx), glev(ix,il,kx)
+    real(p) :: g(ix,il,2), go(ix,il), dmp(mx,nx), dmp1(mx,nx), glev(ix,il,kx), glev2(ix,il,kx)
+    complex(p) :: slev2(mx,nx,kx)
     integer :: kc(kx), k
     character(len=512) :: fin, fout
 
@@ -41,6 +42,10 @@ program dropin_driver
     hk = spdy_do_horizontal_diffusion(tk, sk, dmp, dmp1); write(11) hk
     call spdy_initialize_implicit(real(4800, p))
     call spdy_implicit_terms_f(sk, tk, ps); write(11) sk, tk, ps
+    ! operator + transform sequences over a level stack (one call each)
+    call uvspec_to_grid_levels(kx, sk, tk, glev, glev2); write(11) glev, glev2
+    call grad_to_grid_levels(kx, sk, glev, glev2);       write(11) glev, glev2
+    call vdspec_levels(kx, glev, glev2, slev, slev2, 2); write(11) slev, slev2
     close(11)
     call finalize_spectral
 end program

@@ -193,6 +193,21 @@ class Spectral:
         check(self.lib.spdy_vdspec(self.h, nb, _p(ug), _p(vg), _p(vor), _p(div), int(kcos)))
         return vor, div
 
+    def uvspec_to_grid(self, vorm, divm, kcos=2):
+        """uvspec + spec_to_grid(., kcos) of both results in one call (tendencies.f90:98-100); leading batch dims allowed."""
+        vorm, lead, nb = self._in(vorm, self.spec_shape, np.complex128)
+        divm, _, _ = self._in(divm, self.spec_shape, np.complex128)
+        ug, vg = np.zeros(lead + self.grid_shape), np.zeros(lead + self.grid_shape)
+        check(self.lib.spdy_uvspec_to_grid(self.h, nb, _p(vorm), _p(divm), _p(ug), _p(vg), int(kcos)))
+        return ug, vg
+
+    def grad_to_grid(self, psi, kcos=2):
+        """grad + spec_to_grid(., kcos) of both results in one call (tendencies.f90:121-123)."""
+        psi, lead, nb = self._in(psi, self.spec_shape, np.complex128)
+        gx, gy = np.zeros(lead + self.grid_shape), np.zeros(lead + self.grid_shape)
+        check(self.lib.spdy_grad_to_grid(self.h, nb, _p(psi), _p(gx), _p(gy), int(kcos)))
+        return gx, gy
+
     # ------------------------------------------------------------------ spectral-space tail
     def do_horizontal_diffusion(self, field, fdt_in, dmp, dmp1):
         """horizontal_diffusion.f90:86-105 (2-D or 3-D by the leading dimension)."""

@@ -96,4 +96,17 @@ def test_dropin_module_vs_oracle(tag, tmp_path, oracle_factory):
     ok(take((kx,) + sp, True), o.hdiff(tk, sk, dmp, dmp1))
     rd, rt, rp = o.implicit_terms(sk, tk, ps)
     ok(take((kx,) + sp, True), rd); ok(take((kx,) + sp, True), rt); ok(take(sp, True), rp)
+    # level-stack sequences in one call each; inputs: the *updated* sk, tk written back by implicit_terms above
+    ug, vg = take((kx,) + gr, False), take((kx,) + gr, False)
+    for k in range(kx):
+        ru, rv = o.uvspec(rd[k], rt[k])
+        ok(ug[k], o.spec_to_grid(ru, 2)); ok(vg[k], o.spec_to_grid(rv, 2))
+    gx, gy = take((kx,) + gr, False), take((kx,) + gr, False)
+    for k in range(kx):
+        rdx, rdy = o.grad(rd[k])
+        ok(gx[k], o.spec_to_grid(rdx, 2)); ok(gy[k], o.spec_to_grid(rdy, 2))
+    vorl, divl = take((kx,) + sp, True), take((kx,) + sp, True)
+    for k in range(kx):
+        a, b = o.vdspec(gx[k], gy[k], 2)
+        ok(vorl[k], a); ok(divl[k], b)
     assert pos[0] == raw.size

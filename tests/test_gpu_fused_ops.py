@@ -72,3 +72,28 @@ def test_vdspec_one_pass(nb, kcos, oracle_factory):
         rvor, rdiv = o.vdspec(G[b], G[nb + b], kcos)
         ok(outs[1][0][b], rvor); ok(outs[1][1][b], rdiv)
     sp.close()
+
+
+@pytest.mark.parametrize("res,nb", [("t30", 1), ("t30", 8), ("t30", 300), ("t63", 3)])
+def test_host_pointer_level_stacks(res, nb, oracle_factory):
+    """The host-pointer forms the Fortran level-stack extensions call; a large stack also exercises that the
+    one-pass vdspec never reads a grid that another workgroup's output has overwritten."""
+    import speedy_f90_amd as s
+    o = oracle_factory(res)
+    sp = s.Spectral(res, kx=8, max_batch=max(nb, 8), device=0)
+    S = synth.spectra(2 * nb, sp.trunc, first=1300, full_rows=True)
+    G = synth.grids(2 * nb, sp.ix, sp.il, first=1300)
+    ug, vg = sp.uvspec_to_grid(S[:nb], S[nb:], 2)
+    gx, gy = sp.grad_to_grid(S[:nb], 2)
+    vor, div = sp.vdspec(G[:nb], G[nb:], 2)
+    for b in sorted({0, nb // 3, nb - 1}):
+        ru, rv = o.uvspec(S[b], S[nb + b])
+        ok(ug[b], o.spec_to_grid(ru, 2)); ok(vg[b], o.spec_to_grid(rv, 2))
+        rdx, rdy = o.grad(S[b])
+        ok(gx[b], o.spec_to_grid(rdx, 2)); ok(gy[b], o.spec_to_grid(rdy, 2))
+        a, c = o.vdspec(G[b], G[nb + b], 2)
+        ok(vor[b], a); ok(div[b], c)
+    # whole-stack consistency with the one-field-at-a-time calls of the same library
+    one_vor, one_div = sp.vdspec(G[nb - 1], G[2 * nb - 1], 2)
+    assert np.array_equal(vor[nb - 1], one_vor) and np.array_equal(div[nb - 1], one_div)
+    sp.close()
