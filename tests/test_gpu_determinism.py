@@ -1,0 +1,52 @@
+"""Races in the persistent, barrier-synchronised kernels would show up as run-to-run differences or as a
+dependence of a field's result on its position in the batch.  Every entry point must be bit-reproducible."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("res,fused,sizes", [("t30", 1, (1, 2, 3, 255, 256, 257, 511, 513, 1031, 2049)),
+                                              ("t30", 0, (1, 7, 65, 513)),
+                                              ("t63", -1, (1, 9, 65, 200))])
+def test_repeatable_and_position_independent(res, fused, sizes):
+    import torch
+    import speedy_f90_amd as s
+    nmax = max(sizes)
+    sp = s.Spectral(res, kx=8, max_batch=nmax, device=0)
+    sp.set_fused(fused)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12345)
+    G = torch.from_numpy(rng.uniform(-0.5, 0.5, (nmax, sp.il, sp.ix))).to(dev)
+    torch.cuda.synchronize()
+    spec_ref = grid_ref = None
+    for nb in sizes:
+        runs = []
+        for rep in range(3):
+            spec = torch.full((nb, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
+            out = torch.full((nb, sp.il, sp.ix), float("nan"), dtype=torch.float64, device=dev)
+            vor = torch.full((nb // 2, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
+            div = torch.full_like(vor, float("nan"))
+            sp.grid_to_spec_dev(G[:nb], spec)
+            sp.spec_to_grid_dev(spec, out, kcos=2)
+            if nb >= 2:
+                sp.vdspec_dev(G[:nb // 2], G[nb // 2:2 * (nb // 2)], vor, div, 2)
+            sp.synchronize()
+            runs.append((spec, out, vor, div))
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b)
+        for a, b in zip(runs[0], runs[2]):
+            assert torch.equal(a, b)
+        assert not torch.isnan(torch.view_as_real(runs[0][0])).any() and not torch.isnan(runs[0][1]).any()
+        if spec_ref is None:
+            spec_ref, grid_ref = runs[0][0][:1].clone(), runs[0][1][:1].clone()
+        # field 0 is the same field in every batch: its result may not depend on the batch around it
+        assert torch.equal(runs[0][0][:1], spec_ref) and torch.equal(runs[0][1][:1], grid_ref)
+        # and the last field of the batch equals the same field transformed alone
+        one_s = torch.zeros((1, sp.nx, sp.mx), dtype=torch.complex128, device=dev)
+        one_g = torch.zeros((1, sp.il, sp.ix), dtype=torch.float64, device=dev)
+        sp.grid_to_spec_dev(G[nb - 1:nb], one_s); sp.spec_to_grid_dev(one_s, one_g, kcos=2); sp.synchronize()
+        assert torch.equal(runs[0][0][nb - 1:nb], one_s) and torch.equal(runs[0][1][nb - 1:nb], one_g)
+    sp.close()
