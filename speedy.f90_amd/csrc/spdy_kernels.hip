@@ -901,7 +901,8 @@ hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, cons
 {
     if (nb <= 0) return hipSuccess;
     const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
-    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, fft_grid_limit());
+    const int per_cu = 160 * 1024 / ((FFT_ROWS * (p.ix + 1) + 4 * 48 + FFT_ROWS) * 8);   // LDS-resident blocks per CU
+    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, per_cu * fft_grid_limit() / 3);
     if (p.fs != (2 * p.mx + 15) / 16 * 16) return hipErrorInvalidValue;
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_inv_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, four, grid, p.cosgr,
@@ -918,7 +919,8 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
 {
     if (nb <= 0) return hipSuccess;
     const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
-    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, fft_grid_limit());
+    const int per_cu = 160 * 1024 / ((FFT_ROWS * (p.ix + 1) + 4 * 48 + FFT_ROWS) * 8);   // LDS-resident blocks per CU
+    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, per_cu * fft_grid_limit() / 3);
     if (p.fs != (2 * p.mx + 15) / 16 * 16) return hipErrorInvalidValue;
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_dir_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, grid, gscale, four,
