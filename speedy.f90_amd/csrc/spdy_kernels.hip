@@ -415,8 +415,13 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel
     // phase 3: the ido=48 stage, in place.  Butterflies p and 46-p touch the same 4*TPR slots,
     // so one lane does both: 13 work items per row (item 0 = the i=0 and i=47 specials).
     {
-        double *z = tile + r * RS;
-        for (int it = h; it < 13; it += TPR) {
+        // r, h re-derived here: addresses hoisted out of the tile loop get spilled next to the FFT, and the
+        // scratch reload's vmcnt wait would also wait for the next tile's prefetch issued just above
+        int tid3 = tid;
+        asm volatile("" : "+v"(tid3));
+        const int r3 = tid3 & (FFT_ROWS - 1), h3 = tid3 / FFT_ROWS;
+        double *z = tile + r3 * RS;
+        for (int it = h3; it < 13; it += TPR) {
             if (TPR == 2) {        // fftpack radf2, ido=48, l1=1: in(48,1,2) -> out(48,2,1)
                 if (it == 0) {
                     const double a0 = z[0], a1 = z[48], b0 = z[47], b1 = z[95];
@@ -451,28 +456,29 @@ __global__ __launch_bounds__(fft_rows(NF) *(NF / 48), 2) void fourier_dir_kernel
                     z[48] = ti1 - e2;        z[144] = ti1 + e2;
                 } else {
                     const int p = 2 * it - 1, q = 46 - p;
-                    double in[2][8];
-                    UNROLL for (int s = 0; s < 2; ++s) {
-                        const int pp = s == 0 ? p : q;
-                        UNROLL for (int j = 0; j < 4; ++j) { in[s][2 * j] = z[48 * j + pp]; in[s][2 * j + 1] = z[48 * j + pp + 1]; }
-                    }
-                    UNROLL for (int s = 0; s < 2; ++s) {
-                        if (s == 1 && p == q) break;
-                        const int pp = s == 0 ? p : q, qq = s == 0 ? q : p;
-                        const double *a = in[s];
-                        const double cr2 = tw[pp - 1] * a[2] + tw[pp] * a[3];
-                        const double ci2 = tw[pp - 1] * a[3] - tw[pp] * a[2];
-                        const double cr3 = tw[48 + pp - 1] * a[4] + tw[48 + pp] * a[5];
-                        const double ci3 = tw[48 + pp - 1] * a[5] - tw[48 + pp] * a[4];
-                        const double cr4 = tw[96 + pp - 1] * a[6] + tw[96 + pp] * a[7];
-                        const double ci4 = tw[96 + pp - 1] * a[7] - tw[96 + pp] * a[6];
-                        const double sr1 = cr2 + cr4, sr4 = cr4 - cr2, si1 = ci2 + ci4, si4 = ci2 - ci4;
-                        const double si2 = a[1] + ci3, si3 = a[1] - ci3, sr2 = a[0] + cr3, sr3 = a[0] - cr3;
-                        z[pp] = sr1 + sr2;            z[144 + qq] = sr2 - sr1;
-                        z[pp + 1] = si1 + si2;        z[144 + qq + 1] = si1 - si2;
-                        z[96 + pp] = si4 + sr3;       z[48 + qq] = sr3 - si4;
-                        z[96 + pp + 1] = sr4 + si3;   z[48 + qq + 1] = sr4 - si3;
-                    }
+                    // both butterflies' inputs first (each writes slots the other reads), as named scalars: an
+                    // array indexed by the (early-exit) loop variable ended up in scratch memory
+#define RADF4_LOAD(pp_, a0, a1, a2, a3, a4, a5, a6, a7)                                                   \
+    const double a0 = z[pp_], a1 = z[(pp_) + 1], a2 = z[48 + (pp_)], a3 = z[48 + (pp_) + 1],               \
+                 a4 = z[96 + (pp_)], a5 = z[96 + (pp_) + 1], a6 = z[144 + (pp_)], a7 = z[144 + (pp_) + 1]
+#define RADF4_BFLY(pp_, qq_, a0, a1, a2, a3, a4, a5, a6, a7)                                              \
+    do {                                                                                                  \
+        const double cr2 = tw[(pp_) - 1] * a2 + tw[pp_] * a3, ci2 = tw[(pp_) - 1] * a3 - tw[pp_] * a2;     \
+        const double cr3 = tw[48 + (pp_) - 1] * a4 + tw[48 + (pp_)] * a5, ci3 = tw[48 + (pp_) - 1] * a5 - tw[48 + (pp_)] * a4; \
+        const double cr4 = tw[96 + (pp_) - 1] * a6 + tw[96 + (pp_)] * a7, ci4 = tw[96 + (pp_) - 1] * a7 - tw[96 + (pp_)] * a6; \
+        const double sr1 = cr2 + cr4, sr4 = cr4 - cr2, si1 = ci2 + ci4, si4 = ci2 - ci4;                   \
+        const double si2 = a1 + ci3, si3 = a1 - ci3, sr2 = a0 + cr3, sr3 = a0 - cr3;                       \
+        z[pp_] = sr1 + sr2;            z[144 + (qq_)] = sr2 - sr1;                                         \
+        z[(pp_) + 1] = si1 + si2;      z[144 + (qq_) + 1] = si1 - si2;                                     \
+        z[96 + (pp_)] = si4 + sr3;     z[48 + (qq_)] = sr3 - si4;                                          \
+        z[96 + (pp_) + 1] = sr4 + si3; z[48 + (qq_) + 1] = sr4 - si3;                                      \
+    } while (0)
+                    RADF4_LOAD(p, pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7);
+                    RADF4_LOAD(q, qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7);
+                    RADF4_BFLY(p, q, pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7);
+                    if (p != q) RADF4_BFLY(q, p, qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7);
+#undef RADF4_LOAD
+#undef RADF4_BFLY
                 }
             }
         }
