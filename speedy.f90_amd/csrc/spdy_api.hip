@@ -171,11 +171,37 @@ int upload_all(spdy_plan *p)
     int rc;
 #define UP(vec, field) if ((rc = dev_upload(p, vec, &d.field))) return rc
     UP(inv, pa_inv); UP(dir, pa_dir); UP(t.cosgr, cosgr); UP(t.cosgr2, cosgr2);
-    d.pa_inv2 = d.pa_dir2 = nullptr;
+    d.pa_inv2 = d.pa_dir2 = d.img_s2g = d.img_g2s = nullptr;
     if (t.trunc == 30) {
         std::vector<double> inv2, dir2;
         build_packed_tables(t, d.ks_inv, d.js_dir, inv2, dir2);
         UP(inv2, pa_inv2); UP(dir2, pa_dir2);
+        // register images of the fused kernels: wave w, slot s holds zonal wavenumber mslot(s, w) (spdy_fused_t30.inc)
+        auto mslot = [](int sl, int w) { return (sl & 1) ? 4 * sl + 3 - w : 4 * sl + w; };
+        std::vector<double> is2g((size_t)4 * 60 * 64), ig2s((size_t)4 * 72 * 64);
+        for (int w = 0; w < 4; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                int ai = 0;
+                auto put = [&](std::vector<double> &img, int per_wave, double v) {
+                    img[((size_t)(w * (per_wave / 2) + ai / 2) * 64 + lane) * 2 + (ai & 1)] = v;
+                    ++ai;
+                };
+                for (int sl = 0; sl < 8; ++sl) {                                   // inverse: 3 fragments per k-step
+                    const int mc = std::min(mslot(sl, w), t.mx - 1);
+                    for (int ks = 0; ks < 4 - (sl >> 1); ++ks) {
+                        put(is2g, 60, inv[(((size_t)mc * 2 + 0) * 4 + ks) * 2 * 64 + lane]);
+                        put(is2g, 60, inv[(((size_t)mc * 2 + 1) * 4 + ks) * 2 * 64 + lane]);
+                        put(is2g, 60, inv2[((size_t)mc * 4 + ks) * 64 + lane]);
+                    }
+                }
+                ai = 0;
+                for (int sl = 0; sl < 8; ++sl) {                                   // direct: 12 / 6 fragments per slot
+                    const int mc = std::min(mslot(sl, w), t.mx - 1);
+                    if (sl < 4) for (int q = 0; q < 12; ++q) put(ig2s, 72, dir[((size_t)mc * 2 * 6 + q) * 64 + lane]);
+                    else for (int q = 0; q < 6; ++q) put(ig2s, 72, dir2[((size_t)mc * 6 + q) * 64 + lane]);
+                }
+            }
+        UP(is2g, img_s2g); UP(ig2s, img_g2s);
     }
     UP(t.el2, el2); UP(t.elm2, elm2); UP(t.trfilt, trfilt); UP(t.gradx, gradx); UP(t.gradym, gradym);
     UP(t.gradyp, gradyp); UP(t.uvdx, uvdx); UP(t.uvdym, uvdym); UP(t.uvdyp, uvdyp); UP(t.vddym, vddym);

@@ -17,6 +17,9 @@ struct DevPlan {
     // 4x4x4-block fragments with both parities packed (fused T30 kernels; nullptr otherwise):
     const double *pa_inv2;  // [mx][ks_inv][64]  blocks 0,1: latitudes 16..23 of even n; blocks 2,3: of odd n
     const double *pa_dir2;  // [mx][js_dir][64]  blocks 0,1: n rows 0..7 of even n; blocks 2,3: of odd n
+    // the same fragments in the order the fused T30 kernels keep them in registers, two per 16-byte load:
+    const double *img_s2g;  // [4 Legendre waves][30][64 lanes][2]
+    const double *img_g2s;  // [4 Legendre waves][36][64 lanes][2]
     const double *cosgr;    // [il]
     const double *cosgr2;   // [il]
     // spectral operator tables, each [nx][mx] (gradx: [mx])
