@@ -127,6 +127,15 @@ int spdy_hdiff(spdy_plan *plan, int nlev, const double *field, const double *fdt
                const double *dmp1, double *fdt_out);
 int spdy_hdiff_dev(spdy_plan *plan, int nlev, const double *field, const double *fdt_in, const double *d_dmp,
                    const double *d_dmp1, double *fdt_out);
+/* The seven diffusion calls of one time step (time_stepping.f90:63-96) in one launch: nops <= SPDY_HDIFF_MAX_OPS
+ * independent operations, each as spdy_hdiff_dev would do it (device pointers; ops is a host array).          */
+enum { SPDY_HDIFF_MAX_OPS = 8 };
+typedef struct {
+    int nlev;
+    const double *field, *fdt_in, *d_dmp, *d_dmp1;
+    double *fdt_out;
+} spdy_hdiff_op;
+int spdy_hdiff_multi_dev(spdy_plan *plan, int nops, const spdy_hdiff_op *ops);
 int spdy_implicit_init(spdy_plan *plan, double dt);
 int spdy_implicit_terms(spdy_plan *plan, double *divdt, double *tdt, double *psdt);
 int spdy_implicit_terms_dev(spdy_plan *plan, double *divdt, double *tdt, double *psdt);

@@ -772,6 +772,22 @@ int spdy_hdiff_dev(spdy_plan *p, int nlev, const double *field, const double *fd
     return SPDY_OK;
 }
 
+int spdy_hdiff_multi_dev(spdy_plan *p, int nops, const spdy_hdiff_op *ops)
+{
+    NEED_DEVICE(p);
+    if (nops < 0 || nops > SPDY_HDIFF_MAX_OPS || (nops && !ops)) return fail(SPDY_ERR_ARG, "nops=%d outside [0, %d]", nops, (int)SPDY_HDIFF_MAX_OPS);
+    spdy::HdiffOps h{};
+    h.nops = nops;
+    for (int i = 0; i < nops; ++i) {
+        if (ops[i].nlev < 0 || (ops[i].nlev && (!ops[i].field || !ops[i].fdt_in || !ops[i].d_dmp || !ops[i].d_dmp1 || !ops[i].fdt_out)))
+            return fail(SPDY_ERR_ARG, "hdiff op %d: bad argument", i);
+        h.nlev[i] = ops[i].nlev; h.field[i] = ops[i].field; h.fdt[i] = ops[i].fdt_in;
+        h.dmp[i] = ops[i].d_dmp; h.dmp1[i] = ops[i].d_dmp1; h.out[i] = ops[i].fdt_out;
+    }
+    KERNEL(spdy::launch_hdiff_multi(p->dev, h, p->stream));
+    return SPDY_OK;
+}
+
 int spdy_hdiff(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *dmp,
                const double *dmp1, double *fdt_out)
 {

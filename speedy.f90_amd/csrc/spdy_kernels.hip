@@ -972,6 +972,24 @@ hipError_t launch_uvspec(const DevPlan &p, int nb, const double *vor, const doub
     return hipGetLastError();
 }
 
+// blockIdx.y selects the operation (the seven do_horizontal_diffusion calls of a time step in one launch)
+__global__ void hdiff_multi_kernel(int sz, HdiffOps ops)
+{
+    const int op = blockIdx.y;
+    const long total = (long)ops.nlev[op] * sz, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i % sz);
+    st(ops.out[op], i, ops.dmp1[op][e] * (ld(ops.fdt[op], i) - ops.dmp[op][e] * ld(ops.field[op], i)));
+}
+hipError_t launch_hdiff_multi(const DevPlan &p, const HdiffOps &ops, hipStream_t s)
+{
+    int maxlev = 0;
+    for (int i = 0; i < ops.nops; ++i) maxlev = std::max(maxlev, ops.nlev[i]);
+    const long total = (long)maxlev * p.mx * p.nx;
+    if (ops.nops <= 0 || total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hdiff_multi_kernel, dim3(blocks_for(total).x, ops.nops), dim3(256), 0, s, p.mx * p.nx, ops);
+    return hipGetLastError();
+}
 hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const double *fdt, const double *dmp,
                         const double *dmp1, double *out, hipStream_t s)
 {

@@ -64,6 +64,12 @@ hipError_t launch_vds(const DevPlan &p, int nb, const double *u, const double *v
 hipError_t launch_uvspec(const DevPlan &p, int nb, const double *vor, const double *div, double *u, double *v, hipStream_t s);
 hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const double *fdt, const double *dmp,
                         const double *dmp1, double *out, hipStream_t s);
+struct HdiffOps {   // up to 8 independent diffusion operations, passed by value as one kernel argument
+    int nops, nlev[8];
+    const double *field[8], *fdt[8], *dmp[8], *dmp1[8];
+    double *out[8];
+};
+hipError_t launch_hdiff_multi(const DevPlan &p, const HdiffOps &ops, hipStream_t s);
 hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s);
 
 }  // namespace spdy

@@ -299,6 +299,20 @@ class Spectral:
     def implicit_terms_dev(self, divdt, tdt, psdt):
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
 
+    def hdiff_multi_dev(self, ops):
+        """ops: up to 8 tuples (field, fdt_in, dmp_name, dmp1_name, out) -- the diffusion calls of one time step
+        (time_stepping.f90:63-96) in one launch."""
+        class Op(ctypes.Structure):
+            _fields_ = [("nlev", ctypes.c_int), ("field", ctypes.c_void_p), ("fdt_in", ctypes.c_void_p),
+                        ("d_dmp", ctypes.c_void_p), ("d_dmp1", ctypes.c_void_p), ("fdt_out", ctypes.c_void_p)]
+        arr = (Op * len(ops))()
+        for o, (field, fdt_in, dmp_name, dmp1_name, out) in zip(arr, ops):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            check(self.lib.spdy_device_table(self.h, dmp_name.encode(), ctypes.byref(a)))
+            check(self.lib.spdy_device_table(self.h, dmp1_name.encode(), ctypes.byref(b)))
+            o.nlev, o.field, o.fdt_in, o.d_dmp, o.d_dmp1, o.fdt_out = field.shape[0], field.data_ptr(), fdt_in.data_ptr(), a.value, b.value, out.data_ptr()
+        check(self.lib.spdy_hdiff_multi_dev(self.h, len(ops), ctypes.cast(arr, ctypes.c_void_p)))
+
     def hdiff_dev(self, field, fdt_in, dmp_name, dmp1_name, out):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         check(self.lib.spdy_device_table(self.h, dmp_name.encode(), ctypes.byref(a)))

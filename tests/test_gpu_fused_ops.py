@@ -97,3 +97,32 @@ def test_host_pointer_level_stacks(res, nb, oracle_factory):
     one_vor, one_div = sp.vdspec(G[nb - 1], G[2 * nb - 1], 2)
     assert np.array_equal(vor[nb - 1], one_vor) and np.array_equal(div[nb - 1], one_div)
     sp.close()
+
+
+def test_hdiff_multi_equals_separate_calls(oracle_factory):
+    """The seven diffusion calls of a time step in one launch (spdy_hdiff_multi_dev) = the same calls one by one."""
+    import torch
+    import speedy_f90_amd as s
+    from golden.make_golden import tail_inputs
+    o = oracle_factory("t30")
+    sp = s.Spectral("t30", kx=8, max_batch=16, device=0)
+    sp.initialize_implicit(4800.0); o.tail_init(4800.0)
+    names = [("dmp", "dmp1"), ("dmpd", "dmp1d"), ("dmp", "dmp1"), ("dmp", "dmp1"), ("dmps", "dmp1s"), ("dmps", "dmp1s"), ("dmpd", "dmp1d")]
+    nlevs = [8, 8, 8, 8, 8, 8, 1]
+    ops, want = [], []
+    for i, ((a, b), nl) in enumerate(zip(names, nlevs)):
+        f = torch.from_numpy(synth.spectra(nl, 30, first=2000 + 10 * i, full_rows=True)).cuda()
+        t = torch.from_numpy(synth.spectra(nl, 30, first=3000 + 10 * i, full_rows=True)).cuda()
+        single = torch.zeros_like(f)
+        sp.hdiff_dev(f, t, a, b, single)
+        out = torch.full_like(f, float("nan"))
+        ops.append((f, t, a, b, out)); want.append(single)
+    sp.hdiff_multi_dev(ops)
+    sp.synchronize()
+    for (f, t, a, b, out), single in zip(ops, want):
+        assert torch.equal(out, single)
+    f, t, a, b, out = ops[1]
+    ok(out.cpu().numpy(), o.hdiff(f.cpu().numpy(), t.cpu().numpy(), o.table(a).reshape(sp.nx, sp.mx), o.table(b).reshape(sp.nx, sp.mx)))
+    with pytest.raises(s.SpdyError):
+        sp.hdiff_multi_dev(ops + ops)                       # 14 > SPDY_HDIFF_MAX_OPS
+    sp.close()

@@ -34,10 +34,16 @@ ugr, vgr = torch.zeros((2 * kx, sp.il, sp.ix), dtype=f64, device=dev), torch.zer
 names = [("dmp", "dmp1"), ("dmpd", "dmp1d"), ("dmp", "dmp1"), ("dmp", "dmp1"), ("dmps", "dmp1s"), ("dmps", "dmp1s"), ("dmpd", "dmp1d")]
 
 
+MULTI = True
+
+
 def tail():
     sp.grid_to_spec_dev(G[:25], S2)
-    for i, (a, b) in enumerate(names):
-        sp.hdiff_dev(fld[i], fdt[i], a, b, out[i])
+    if MULTI:
+        sp.hdiff_multi_dev([(fld[i], fdt[i], a, b, out[i]) for i, (a, b) in enumerate(names)])
+    else:
+        for i, (a, b) in enumerate(names):
+            sp.hdiff_dev(fld[i], fdt[i], a, b, out[i])
     sp.implicit_terms_dev(out[1], out[0], psdt)
 
 
@@ -67,7 +73,15 @@ def timeit(fn, n=200):
 
 
 print("T30 L8 spectral-side step: 91 inverse + 73 direct transforms, uvspec, vds, 7 hdiff, implicit_terms")
-for label, fn in (("operator kernels + batched transforms", step_calls), ("uvspec folded into the inverse transform", step_fused)):
+def step_calls_7():
+    global MULTI
+    MULTI = False
+    step_calls()
+    MULTI = True
+
+
+for label, fn in (("7 hdiff launches, batched transforms", step_calls_7), ("one hdiff launch, batched transforms", step_calls),
+                  ("one hdiff launch, uvspec folded into s2g", step_fused)):
     eager = timeit(fn)
     with sp.graph_capture() as g:
         fn()
