@@ -153,6 +153,12 @@ int spdy_device_table(spdy_plan *plan, const char *name, const double **d_ptr);
 int spdy_uvspec_to_grid_dev(spdy_plan *plan, int nb, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
                             int kcos);
 int spdy_grad_to_grid_dev(spdy_plan *plan, int nb, const double *d_psi, double *d_gx, double *d_gy, int kcos);
+/* One model step's whole direct batch in one launch (tendencies.f90:212-234: vdspec of 3*kx (u,v) pairs next to
+ * grid_to_spec of the remaining fields): at these sizes every launch costs its ~10 us pipeline latency, whatever it
+ * carries.  Equals spdy_vdspec_dev(npairs, ...) followed by spdy_grid_to_spec_dev(nplain, ...); the two groups must
+ * not overlap in memory.                                                                                       */
+int spdy_direct_batch_dev(spdy_plan *plan, int npairs, const double *d_ug, const double *d_vg, double *d_vorm,
+                          double *d_divm, int kcos, int nplain, const double *d_grid, double *d_spec);
 /* the same with host pointers (one H2D + one D2H round trip for a whole level stack) */
 int spdy_uvspec_to_grid(spdy_plan *plan, int nb, const double *vor, const double *div, double *ug, double *vg, int kcos);
 int spdy_grad_to_grid(spdy_plan *plan, int nb, const double *psi, double *gx, double *gy, int kcos);

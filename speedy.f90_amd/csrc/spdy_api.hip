@@ -685,6 +685,24 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
     return SPDY_OK;
 }
 
+int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const double *vg, double *vorm, double *divm, int kcos,
+                          int nplain, const double *grid, double *spec)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, npairs));
+    RC(check_batch(p, nplain));
+    if ((npairs && (!ug || !vg || !vorm || !divm)) || (nplain && (!grid || !spec))) return fail(SPDY_ERR_ARG, "null device pointer");
+    if (use_fused(p, npairs) && npairs > 0 && nplain > 0) {
+        const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
+        return timed(p, SPDY_K_G2S_FUSED, [&] {
+            return spdy::launch_g2s_fused(p->dev, npairs, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm, nplain, grid, spec);
+        });
+    }
+    if (npairs) RC(spdy_vdspec_dev(p, npairs, ug, vg, vorm, divm, kcos));
+    if (nplain) RC(spdy_grid_to_spec_dev(p, nplain, grid, spec));
+    return SPDY_OK;
+}
+
 #define HOST_1IN_1OUT(name, devfn)                                                 \
     int name(spdy_plan *p, int nb, const double *in, double *out)                  \
     {                                                                              \

@@ -54,8 +54,11 @@ hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const 
                             int max_wg, hipStream_t s, int mode = 0, const double *spec2 = nullptr, double *grid2 = nullptr);
 // grid2 / spec2 non-null: vdspec in one pass -- tile i is the pair (grid[i], grid2[i]) scaled by gscale, the
 // outputs are vds of the pair's spectra: vorticity -> spec, divergence -> spec2 (nb pairs)
+// nplain > 0: a model step's whole direct batch in one launch -- nb (u,v) pairs as above plus nplain ordinary fields
+// grid_p -> spec_p (unscaled)
 hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg,
-                            hipStream_t s, const double *grid2 = nullptr, double *spec2 = nullptr);
+                            hipStream_t s, const double *grid2 = nullptr, double *spec2 = nullptr, int nplain = 0,
+                            const double *grid_p = nullptr, double *spec_p = nullptr);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };
 hipError_t launch_scale_op(const DevPlan &p, int op, int nb, const double *in, double *out, hipStream_t s);

@@ -296,6 +296,11 @@ class Spectral:
         """grad followed by spec_to_grid(., kcos) of both results (tendencies.f90:121-123), one pass at T30."""
         check(self.lib.spdy_grad_to_grid_dev(self.h, psi.shape[0], self._dp(psi), self._dp(gx), self._dp(gy), int(kcos)))
 
+    def direct_batch_dev(self, ug, vg, vor, div, grid, spec, kcos=2):
+        """vdspec of the (ug, vg) pairs and grid_to_spec of `grid` in one launch (a model step's direct batch)."""
+        check(self.lib.spdy_direct_batch_dev(self.h, ug.shape[0], self._dp(ug), self._dp(vg), self._dp(vor), self._dp(div), int(kcos),
+                                             grid.shape[0], self._dp(grid), self._dp(spec)))
+
     def implicit_terms_dev(self, divdt, tdt, psdt):
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
 

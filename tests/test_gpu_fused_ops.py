@@ -126,3 +126,23 @@ def test_hdiff_multi_equals_separate_calls(oracle_factory):
     with pytest.raises(s.SpdyError):
         sp.hdiff_multi_dev(ops + ops)                       # 14 > SPDY_HDIFF_MAX_OPS
     sp.close()
+
+
+@pytest.mark.parametrize("res,npairs,nplain", [("t30", 24, 25), ("t30", 1, 1), ("t30", 3, 8), ("t30", 300, 301), ("t63", 3, 5)])
+def test_direct_batch_one_launch(res, npairs, nplain):
+    """spdy_direct_batch_dev = vdspec of the pairs + grid_to_spec of the plain fields, bit for bit."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral(res, kx=8, max_batch=max(npairs, nplain, 8), device=0)
+    G = torch.from_numpy(synth.grids(2 * npairs + nplain, sp.ix, sp.il, first=4000)).cuda()
+    ug, vg, gp = G[:npairs], G[npairs:2 * npairs], G[2 * npairs:]
+    cs = (sp.nx, sp.mx)
+    want = [torch.zeros((n,) + cs, dtype=torch.complex128, device="cuda") for n in (npairs, npairs, nplain)]
+    sp.vdspec_dev(ug, vg, want[0], want[1], 2)
+    sp.grid_to_spec_dev(gp, want[2])
+    got = [torch.full((n,) + cs, float("nan"), dtype=torch.complex128, device="cuda") for n in (npairs, npairs, nplain)]
+    sp.direct_batch_dev(ug, vg, got[0], got[1], gp, got[2], 2)
+    sp.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    sp.close()
