@@ -157,6 +157,11 @@ int spdy_grad_to_grid_dev(spdy_plan *plan, int nb, const double *d_psi, double *
  * grid_to_spec of the remaining fields): at these sizes every launch costs its ~10 us pipeline latency, whatever it
  * carries.  Equals spdy_vdspec_dev(npairs, ...) followed by spdy_grid_to_spec_dev(nplain, ...); the two groups must
  * not overlap in memory.                                                                                       */
+/* ... and its whole inverse batch (tendencies.f90:89-107: uvspec + two spec_to_grid(.,2) per level next to the
+ * spec_to_grid of the other fields).  Equals spdy_uvspec_to_grid_dev(npairs, ..., kcos_pairs) followed by
+ * spdy_spec_to_grid_dev(nplain, d_spec, d_kcos, kcos_all, d_grid).                                          */
+int spdy_inverse_batch_dev(spdy_plan *plan, int npairs, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
+                           int kcos_pairs, int nplain, const double *d_spec, const int *d_kcos, int kcos_all, double *d_grid);
 int spdy_direct_batch_dev(spdy_plan *plan, int npairs, const double *d_ug, const double *d_vg, double *d_vorm,
                           double *d_divm, int kcos, int nplain, const double *d_grid, double *d_spec);
 /* the same with host pointers (one H2D + one D2H round trip for a whole level stack) */

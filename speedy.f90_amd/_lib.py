@@ -59,6 +59,7 @@ SIGNATURES = {
     "spdy_grad_to_grid": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int],
     "spdy_hdiff_multi_dev": [c_void_p, c_int, c_void_p],
     "spdy_direct_batch_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "spdy_inverse_batch_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "spdy_graph_begin": [c_void_p],
     "spdy_graph_end": [c_void_p, ctypes.POINTER(c_void_p)],
     "spdy_graph_launch": [c_void_p],

@@ -685,6 +685,24 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
     return SPDY_OK;
 }
 
+int spdy_inverse_batch_dev(spdy_plan *p, int npairs, const double *vor, const double *dv, double *ug, double *vg, int kcos_pairs,
+                           int nplain, const double *spec, const int *d_kcos, int kcos_all, double *grid)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, npairs));
+    RC(check_batch(p, nplain));
+    if ((npairs && (!vor || !dv || !ug || !vg)) || (nplain && (!spec || !grid))) return fail(SPDY_ERR_ARG, "null device pointer");
+    if (kcos_pairs != 1 && kcos_pairs != 2) return fail(SPDY_ERR_ARG, "kcos must be 1 or 2");
+    if (use_fused(p, npairs) && npairs > 0 && nplain > 0)
+        return timed(p, SPDY_K_S2G_FUSED, [&] {
+            return spdy::launch_s2g_fused(p->dev, npairs, vor, nullptr, kcos_pairs, ug, p->num_cu * p->wg_per_cu, p->stream, 3, dv, vg,
+                                          nplain, spec, d_kcos, kcos_all, grid);
+        });
+    if (npairs) RC(spdy_uvspec_to_grid_dev(p, npairs, vor, dv, ug, vg, kcos_pairs));
+    if (nplain) RC(spdy_spec_to_grid_dev(p, nplain, spec, d_kcos, kcos_all, grid));
+    return SPDY_OK;
+}
+
 int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const double *vg, double *vorm, double *divm, int kcos,
                           int nplain, const double *grid, double *spec)
 {

@@ -50,8 +50,12 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
 // mode 0: plain.  mode 1: uvspec fused -- tile i = (vor[i], div[i]) = (spec, spec2) -> (ug, vg) = (grid, grid2).
 // mode 2: grad fused -- tile i = psi[i] = spec -> (d/dx, d/dy) = (grid, grid2).  In modes 1/2 nb counts tiles and
 // kcos_all applies to both outputs.
+// mode 3: a model step's whole inverse batch in one launch -- nb (vor, div) pairs as in mode 1 plus nplain ordinary
+// fields spec_p -> grid_p with their own kcos (kcos_p per field, or kcos_all_p)
 hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid,
-                            int max_wg, hipStream_t s, int mode = 0, const double *spec2 = nullptr, double *grid2 = nullptr);
+                            int max_wg, hipStream_t s, int mode = 0, const double *spec2 = nullptr, double *grid2 = nullptr,
+                            int nplain = 0, const double *spec_p = nullptr, const int *kcos_p = nullptr, int kcos_all_p = 1,
+                            double *grid_p = nullptr);
 // grid2 / spec2 non-null: vdspec in one pass -- tile i is the pair (grid[i], grid2[i]) scaled by gscale, the
 // outputs are vds of the pair's spectra: vorticity -> spec, divergence -> spec2 (nb pairs)
 // nplain > 0: a model step's whole direct batch in one launch -- nb (u,v) pairs as above plus nplain ordinary fields

@@ -296,6 +296,12 @@ class Spectral:
         """grad followed by spec_to_grid(., kcos) of both results (tendencies.f90:121-123), one pass at T30."""
         check(self.lib.spdy_grad_to_grid_dev(self.h, psi.shape[0], self._dp(psi), self._dp(gx), self._dp(gy), int(kcos)))
 
+    def inverse_batch_dev(self, vor, div, ug, vg, spec, grid, kcos_pairs=2, kcos=1, d_kcos=None):
+        """uvspec + spec_to_grid(., kcos_pairs) of the (vor, div) pairs and spec_to_grid of `spec` in one launch."""
+        check(self.lib.spdy_inverse_batch_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(ug), self._dp(vg), int(kcos_pairs),
+                                              spec.shape[0], self._dp(spec), self._dp(d_kcos) if d_kcos is not None else None, int(kcos),
+                                              self._dp(grid)))
+
     def direct_batch_dev(self, ug, vg, vor, div, grid, spec, kcos=2):
         """vdspec of the (ug, vg) pairs and grid_to_spec of `grid` in one launch (a model step's direct batch)."""
         check(self.lib.spdy_direct_batch_dev(self.h, ug.shape[0], self._dp(ug), self._dp(vg), self._dp(vor), self._dp(div), int(kcos),

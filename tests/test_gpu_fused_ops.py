@@ -146,3 +146,24 @@ def test_direct_batch_one_launch(res, npairs, nplain):
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     sp.close()
+
+
+@pytest.mark.parametrize("res,npairs,nplain", [("t30", 16, 59), ("t30", 1, 1), ("t30", 5, 2), ("t30", 300, 299), ("t63", 3, 5)])
+def test_inverse_batch_one_launch(res, npairs, nplain):
+    """spdy_inverse_batch_dev = uvspec_to_grid of the pairs + spec_to_grid of the plain fields (mixed kcos), bit for bit."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral(res, kx=8, max_batch=max(npairs, nplain, 8), device=0)
+    S = torch.from_numpy(synth.spectra(2 * npairs + nplain, sp.trunc, first=5000, full_rows=True)).cuda()
+    vor, div, spl = S[:npairs], S[npairs:2 * npairs], S[2 * npairs:]
+    kc = torch.tensor([1 + (i % 3 == 0) for i in range(nplain)], dtype=torch.int32, device="cuda")
+    gs = (sp.il, sp.ix)
+    want = [torch.zeros((n,) + gs, dtype=torch.float64, device="cuda") for n in (npairs, npairs, nplain)]
+    sp.uvspec_to_grid_dev(vor, div, want[0], want[1], 2)
+    sp.spec_to_grid_dev(spl, want[2], d_kcos=kc)
+    got = [torch.full((n,) + gs, float("nan"), dtype=torch.float64, device="cuda") for n in (npairs, npairs, nplain)]
+    sp.inverse_batch_dev(vor, div, got[0], got[1], spl, got[2], kcos_pairs=2, d_kcos=kc)
+    sp.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    sp.close()

@@ -54,6 +54,13 @@ def step_calls():          # the reference's call sequence, batched: uvspec, the
     tail()
 
 
+def step_batches():        # one launch per batch: inverse (uvspec pairs + plain), direct (vdspec pairs + plain), hdiff, implicit
+    sp.inverse_batch_dev(S[:2 * kx], S[2 * kx:4 * kx], ugr, vgr, S[:59], G[:59], kcos_pairs=2, kcos=1)
+    sp.direct_batch_dev(ug, vg, vor, div, G[:25], S2, 2)
+    sp.hdiff_multi_dev([(fld[i], fdt[i], a, b, out[i]) for i, (a, b) in enumerate(names)])
+    sp.implicit_terms_dev(out[1], out[0], psdt)
+
+
 def step_fused():          # uvspec folded into its 32 inverse transforms; the other 59 as one batch
     sp.uvspec_to_grid_dev(S[:2 * kx], S[2 * kx:4 * kx], ugr, vgr, 2)
     sp.spec_to_grid_dev(S[:59], G[:59], kcos=1)
@@ -81,7 +88,8 @@ def step_calls_7():
 
 
 for label, fn in (("7 hdiff launches, batched transforms", step_calls_7), ("one hdiff launch, batched transforms", step_calls),
-                  ("one hdiff launch, uvspec folded into s2g", step_fused)):
+                  ("one hdiff launch, uvspec folded into s2g", step_fused),
+                  ("four launches: inverse batch, direct batch, hdiff, implicit", step_batches)):
     eager = timeit(fn)
     with sp.graph_capture() as g:
         fn()
