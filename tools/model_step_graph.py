@@ -14,7 +14,8 @@ import speedy_f90_amd as s
 import synth
 
 kx = 8
-sp = s.Spectral("t30", kx=kx, max_batch=128, device=0)
+RES = sys.argv[1] if len(sys.argv) > 1 else "t30"
+sp = s.Spectral(RES, kx=kx, max_batch=128, device=0)
 sp.initialize_implicit(4800.0)
 dev = torch.device("cuda", 0)
 c128, f64 = torch.complex128, torch.float64
@@ -79,7 +80,7 @@ def timeit(fn, n=200):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-print("T30 L8 spectral-side step: 91 inverse + 73 direct transforms, uvspec, vds, 7 hdiff, implicit_terms")
+print("%s L8 spectral-side step: 91 inverse + 73 direct transforms, uvspec, vds, 7 hdiff, implicit_terms" % RES.upper())
 def step_calls_7():
     global MULTI
     MULTI = False
@@ -98,7 +99,7 @@ for label, fn in (("7 hdiff launches, batched transforms", step_calls_7), ("one 
     g.close()
 try:
     from oracle.pyoracle import Reference
-    ref = Reference("t30")
+    ref = Reference(RES)
     import numpy as np
     Gh = synth.grids(82, ref.ix, ref.il, first=0)       # (91 + 73) / 2 round trips
     t0 = time.perf_counter(); ref.roundtrip_loop(Gh, 5); dt = (time.perf_counter() - t0) / 5
