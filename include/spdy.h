@@ -39,20 +39,34 @@ enum {
     SPDY_ERR_NO_DEVICE = -3,    /* no HIP device / host-only plan used for compute             */
     SPDY_ERR_HIP = -4,          /* a HIP runtime call failed                                  */
     SPDY_ERR_STATE = -5,        /* e.g. implicit_terms before implicit_init                    */
-    SPDY_ERR_TABLE = -6         /* generated table failed its pinned-value self check          */
+    SPDY_ERR_TABLE = -6,        /* generated table failed its pinned-value self check          */
+    SPDY_ERR_COMM = -7          /* RCCL could not be loaded / a collective failed              */
 };
 
 /* ---- plan ------------------------------------------------------------------------------
  * Replaces the private module state filled by initialize_geometry (geometry.f90:35),
  * initialize_fourier (fourier.f90:18), initialize_legendre (legendre.f90:23),
  * initialize_spectral (spectral.f90:20) and initialize_horizontal_diffusion
- * (horizontal_diffusion.f90:36).  Supported: (trunc,ix,iy) = (30,96,24) and (63,192,48);
- * kx in {5,7,8} for the implicit solve (geometry.f90:42-48), any kx >= 1 otherwise.
- * device >= 0 selects a HIP device; device = -1 builds a host-only plan (tables only: lets
- * CPU-side tests inspect tables; every compute call on it returns SPDY_ERR_NO_DEVICE).
- * max_batch bounds nb of every batched call (sizes the Fourier workspace).                 */
+ * (horizontal_diffusion.f90:36).  Supported: (trunc,ix,iy) = (30,96,24) and (63,192,48); 1 <= kx <= SPDY_MAX_KX.
+ * Transforms, operators and do_horizontal_diffusion are level-agnostic.  Everything that needs sigma levels
+ * (implicit solve, geopotential, spectral tendencies, the diffusion block's orographic correction) works out of the
+ * box for kx in {5,7,8} -- the only sets the reference defines (geometry.f90:42-48) -- and for any other kx after
+ * spdy_plan_set_sigma.
+ * device >= 0 selects a HIP device; device = SPDY_DEVICE_AUTO takes $SPDY_DEVICE, else the process's local rank
+ * ($LOCAL_RANK, $OMPI_COMM_WORLD_LOCAL_RANK, $SLURM_LOCALID) modulo the visible devices, else device 0;
+ * device = SPDY_DEVICE_NONE builds a host-only plan (tables only: lets CPU-side tests inspect tables; every compute
+ * call on it returns SPDY_ERR_NO_DEVICE).
+ * max_batch bounds nb of every batched call.  Device memory beyond the tables (< 10 MB) is allocated on demand:
+ * the host-pointer entry points stage through 4 x max_batch grids from their first call on, the four-kernel path
+ * (T63, or spdy_plan_set_fused(0)) keeps a Fourier workspace of max_batch x il x 2mx doubles.  Destroying a plan
+ * also invalidates the graphs captured from it (spdy_graph_launch then returns SPDY_ERR_STATE).          */
+enum { SPDY_MAX_KX = 32, SPDY_DEVICE_NONE = -1, SPDY_DEVICE_AUTO = -2 };
 int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan);
 int spdy_plan_destroy(spdy_plan *plan);
+/* Half levels hsg[kx+1] (strictly increasing within [0,1]) for a level count the reference has no set for -- or
+ * to override its set.  Rebuilds dhs, fsg, dhsr, fsgr (geometry.f90:51-60) and the tables derived from them
+ * (geopotential.f90:22-30, horizontal_diffusion.f90:70-82); spdy_implicit_init must be called (again) afterwards. */
+int spdy_plan_set_sigma(spdy_plan *plan, const double *hsg);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the plan's own. */
 int spdy_plan_set_stream(spdy_plan *plan, void *hip_stream);
 int spdy_plan_synchronize(spdy_plan *plan);
@@ -73,7 +87,8 @@ const char *spdy_last_error(void);
 /* Copy a named host table into buf (up to cap doubles); returns the element count or <0.
  * Names: sia_half coa_half cosgr cosgr2 hsg dhs fsg dhsr fsgr work ifac epsi wt poly nsh2
  *        el2 elm2 el4 trfilt gradx gradym gradyp uvdx uvdym uvdyp vddym vddyp
- *        dmp dmpd dmps dmp1 dmp1d dmp1s tref tref1 tref2 tref3 xc xd xj dhsx elz          */
+ *        dmp dmpd dmps dmp1 dmp1d dmp1s tref tref1 tref2 tref3 xc xd xj dhsx elz
+ *        xgeop1 xgeop2 corf tcorv qcorv coriol                                             */
 int spdy_get_table(const spdy_plan *plan, const char *name, double *buf, int cap);
 
 /* ---- grid <-> spectral transforms --------------------------------------------------------
@@ -142,6 +157,52 @@ int spdy_implicit_terms_dev(spdy_plan *plan, double *divdt, double *tdt, double 
 /* Device copies of the plan's damping tables for spdy_hdiff_dev: name in
  * {dmp,dmpd,dmps,dmp1,dmp1d,dmp1s}; *d_ptr stays valid until the next spdy_implicit_init.     */
 int spdy_device_table(spdy_plan *plan, const char *name, const double **d_ptr);
+
+/* ---- spectral side of a time step (device-resident prognostics) ---------------------------------------------
+ * With these a host keeps vor, div, t, ps, tr in HBM across steps: everything between the direct transforms of one
+ * step and the inverse transforms of the next runs on the device (and can be captured into one graph).
+ *   get_geopotential(t, phis) -> phi                         geopotential.f90:33-57
+ *   get_spectral_tendencies(divdt, tdt, psdt, j2)            tendencies.f90:242-293: div, t, ps are the time-level-j2
+ *       slabs of the prognostics, phis the surface geopotential; phi is written like the reference's module variable
+ *   the diffusion block of step()                            time_stepping.f90:62-96: seven do_horizontal_diffusion
+ *       calls with the orographic corrections ctmp = t + tcorh*tcorv(k), tr + qcorh*qcorv(k) and the stratospheric
+ *       zonal-wind drag sdrag folded in; vor..tr are time level 1; tcorh/qcorh are device (mx,nx) complex arrays the
+ *       host owns (forcing.f90 computes them); tr/trdt/qcorh may all be NULL (no tracer; the reference has ntr = 1)
+ *   step_field_2d/3d(j1, dt, eps, input, fdt)                time_stepping.f90:121-167: leapfrog + Robert-Asselin-
+ *       Williams filter; field is (mx,nx,nlev,2) with both time levels, fdt (mx,nx,nlev) is truncated in place as the
+ *       reference does when ix == 4*iy; wil is the caller's params%wil.  Up to SPDY_STEP_MAX_OPS arrays per launch.   */
+int spdy_geopotential(spdy_plan *plan, const double *t, const double *phis, double *phi);
+int spdy_geopotential_dev(spdy_plan *plan, const double *t, const double *phis, double *phi);
+int spdy_spectral_tendencies_dev(spdy_plan *plan, const double *div, const double *t, const double *ps, const double *phis,
+                                 double *divdt, double *tdt, double *psdt, double *phi);
+int spdy_hdiff_step_dev(spdy_plan *plan, const double *vor, const double *div, const double *t, const double *tr,
+                        const double *d_tcorh, const double *d_qcorh, double sdrag,
+                        double *vordt, double *divdt, double *tdt, double *trdt);
+enum { SPDY_STEP_MAX_OPS = 8 };
+typedef struct {
+    int nlev;
+    double *field, *fdt;
+} spdy_step_op;
+int spdy_step_fields_dev(spdy_plan *plan, int nops, const spdy_step_op *ops, int j1, double dt, double eps, double wil);
+int spdy_step_field(spdy_plan *plan, int nlev, int j1, double dt, double eps, double wil, double *field, double *fdt);
+
+/* ---- multi-GPU: the one exchange a level-sharded step needs (one process per GPU, RCCL over xGMI) ------------
+ * The transform batch shards over (field x level) with no communication.  implicit_terms couples all levels of a
+ * coefficient (implicit.f90:174-216), so ranks that own level blocks complete each other's divdt/tdt first.
+ * Rank r of n owns levels [nlev*r/n, nlev*(r+1)/n) (spdy_comm_level_range).  Rank 0 obtains an id with
+ * spdy_comm_unique_id and hands the SPDY_COMM_ID_BYTES bytes to the other ranks by whatever means the host has
+ * (MPI_Bcast, a file, torch.distributed); then every rank calls spdy_comm_create.  Collectives run on the plan's
+ * stream and can be captured into a graph.  RCCL is loaded on first use.                                        */
+typedef struct spdy_comm spdy_comm;
+enum { SPDY_COMM_ID_BYTES = 128 };
+int spdy_comm_unique_id(char *id);
+int spdy_comm_create(spdy_plan *plan, int nranks, int rank, const char *id, spdy_comm **comm);
+int spdy_comm_destroy(spdy_comm *comm);
+int spdy_comm_level_range(const spdy_comm *comm, int nlev, int *lo, int *hi);
+/* in place: d_full[i] are narr full (mx,nx,nlev) stacks in which this rank has filled its own level block */
+int spdy_allgather_levels_dev(spdy_comm *comm, int nlev, int narr, double *const *d_full);
+/* all-gather of the level blocks of divdt and tdt, then implicit_terms on the full columns (every rank) */
+int spdy_implicit_terms_sharded_dev(spdy_comm *comm, double *divdt, double *tdt, double *psdt);
 
 /* ---- fused operator + transform sequences (device-resident; extensions of the reference interface) ------
  * The reference's callers always follow uvspec by two spec_to_grid(.,2) (tendencies.f90:98-100, physics.f90:96-98)

@@ -26,20 +26,24 @@ if [ ! -d "$REF" ] || [ ! -x "$FC" ]; then
 fi
 mkdir -p "$OUT"
 MODS="types params physical_constants geometry fftpack fourier legendre spectral \
-      dynamical_constants matrix_inversion horizontal_diffusion implicit"
+      dynamical_constants matrix_inversion horizontal_diffusion implicit geopotential"
 
-build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock)
-    local tag="$1" prog="$2" tmp srcs=() m
+build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock), $3 = optimisation flags (default -O2),
+                # $4 = sed program for geometry.f90 ('' = stock; see the kx = 5 / 7 builds below)
+    local tag="$1" prog="$2" opt="${3:--O2}" gprog="${4:-}" tmp srcs=() m
     tmp="$(mktemp -d /tmp/speedy_ref_${tag}.XXXXXX)"
     for m in $MODS; do
         if [ "$m" = params ] && [ -n "$prog" ]; then
             sed -e "$prog" "$REF/params.f90" > "$tmp/params.f90"
             srcs+=("$tmp/params.f90")
+        elif [ "$m" = geometry ] && [ -n "$gprog" ]; then
+            sed -e "$gprog" "$REF/geometry.f90" > "$tmp/geometry.f90"
+            srcs+=("$tmp/geometry.f90")
         else
             srcs+=("$REF/$m.f90")
         fi
     done
-    ( cd "$tmp" && "$FC" -O2 -fPIC -shared -w -Wl,-Bsymbolic -o "$OUT/libspeedy_ref_${tag}.so" \
+    ( cd "$tmp" && "$FC" $opt -fPIC -shared -w -Wl,-Bsymbolic -o "$OUT/libspeedy_ref_${tag}.so" \
           "${srcs[@]}" "$HERE/ref_shim.f90" )
     rm -rf "$tmp"
     echo "build_ref: built $OUT/libspeedy_ref_${tag}.so"
@@ -47,6 +51,18 @@ build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock)
 
 newer() { [ -f "$1" ] && [ "$1" -nt "$HERE/ref_shim.f90" ] && [ "$1" -nt "$HERE/build_ref.sh" ]; }
 
+T63='s/trunc = 30 /trunc = 63 /; s/ix = 96 /ix = 192/; s/iy = 24 /iy = 48 /'
 newer "$OUT/libspeedy_ref_t30.so" || build_one t30 ''
-newer "$OUT/libspeedy_ref_t63.so" || build_one t63 \
-    's/trunc = 30 /trunc = 63 /; s/ix = 96 /ix = 192/; s/iy = 24 /iy = 48 /'
+newer "$OUT/libspeedy_ref_t63.so" || build_one t63 "$T63"
+# the reference's other level counts (geometry.f90:42-48) -- and 16 levels, for which it has no sigma set: the
+# test supplies the half levels through the reference's public geometry variables (ref_shim.f90: ref_set_sigma)
+# kx = 5 / 7: flang (unlike gfortran, which only warns) rejects geometry.f90 there, because the statically dead
+# branches for the OTHER level counts assign hsg(:8) / hsg(:9) to an array of kx+1 elements (geometry.f90:45,47).
+# The scratch copy has exactly those dead assignment lines deleted; the live branch is untouched.
+newer "$OUT/libspeedy_ref_t30k5.so" || build_one t30k5 's/kx = 8 /kx = 5 /' -O2 '/hsg(:8) = /d; /hsg(:9) = /d'
+newer "$OUT/libspeedy_ref_t30k7.so" || build_one t30k7 's/kx = 8 /kx = 7 /' -O2 '/hsg(:9) = /d'
+newer "$OUT/libspeedy_ref_t63k16.so" || build_one t63k16 "$T63; s/kx = 8 /kx = 16/"
+# CPU-baseline variant mirroring upstream's -Ofast (gfortran.makefile:18): value-unsafe optimisation allowed, AVX2+FMA
+# (x86-64-v3 rather than -march=native: the .so is built here and timed on the GPU box's host CPU)
+newer "$OUT/libspeedy_ref_t30fast.so" || build_one t30fast '' '-O3 -ffast-math -march=x86-64-v3'
+newer "$OUT/libspeedy_ref_t63fast.so" || build_one t63fast "$T63" '-O3 -ffast-math -march=x86-64-v3'

@@ -148,6 +148,38 @@ class Oracle(_Dims):
         d = _c128(divdt).copy(); t = _c128(tdt).copy(); p = _c128(psdt).copy()
         self.lib.orc_implicit_terms(self.ctx, _ptr(d), _ptr(t), _ptr(p)); return d, t, p
 
+    def set_sigma(self, hsg):
+        """Half levels for a level count the reference has no set for (geometry.f90:42-48)."""
+        hsg = _f64(hsg); assert hsg.shape == (self.kx + 1,)
+        self.lib.orc_set_sigma(self.ctx, _ptr(hsg))
+
+    # --- spectral side of a time step ---
+    def geopotential(self, t, phis):
+        t = _c128(t); phis = _c128(phis); phi = np.empty_like(t)
+        self.lib.orc_geopotential(self.ctx, _ptr(t), _ptr(phis), _ptr(phi)); return phi
+
+    def spectral_tendencies(self, div, t, ps, phis, divdt, tdt, psdt):
+        """tendencies.f90:242-293; returns updated copies (divdt, tdt, psdt, phi)."""
+        div = _c128(div); t = _c128(t); ps = _c128(ps); phis = _c128(phis)
+        a = _c128(divdt).copy(); b = _c128(tdt).copy(); c = _c128(psdt).copy(); phi = np.empty_like(t)
+        self.lib.orc_spectral_tendencies(self.ctx, _ptr(div), _ptr(t), _ptr(ps), _ptr(phis), _ptr(a), _ptr(b), _ptr(c), _ptr(phi))
+        return a, b, c, phi
+
+    def hdiff_step(self, vor, div, t, tr, tcorh, qcorh, sdrag, vordt, divdt, tdt, trdt):
+        """time_stepping.f90:62-96; returns updated copies of the four tendencies."""
+        ins = [_c128(x) for x in (vor, div, t, tr, tcorh, qcorh)]
+        outs = [_c128(x).copy() for x in (vordt, divdt, tdt, trdt)]
+        self.lib.orc_hdiff_step(self.ctx, *[_ptr(x) for x in ins], ctypes.c_double(sdrag), *[_ptr(x) for x in outs])
+        return outs
+
+    def step_field(self, j1, dt, eps, wil, field, fdt):
+        """time_stepping.f90:121-167; field [2, nlev, nx, mx] (or [2, nx, mx]), fdt [nlev, nx, mx]; returns copies."""
+        f = _c128(field).copy(); d = _c128(fdt).copy()
+        nlev = 1 if d.ndim == 2 else d.shape[0]
+        self.lib.orc_step_field(self.ctx, ctypes.c_int(nlev), ctypes.c_int(j1), ctypes.c_double(dt), ctypes.c_double(eps),
+                                ctypes.c_double(wil), _ptr(f), _ptr(d))
+        return f, d
+
     def roundtrip_loop(self, g_in, nrep=1):
         g_in = _f64(g_in); out = np.empty_like(g_in)
         self.lib.orc_roundtrip_loop(self.ctx, ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))
@@ -257,6 +289,23 @@ class Reference(_Dims):
 
     def tail_init(self, dt):
         self.lib.ref_tail_init(ctypes.c_double(dt))
+
+    def set_sigma(self, hsg, dhs, fsg, dhsr, fsgr):
+        """Assign the reference's public sigma-level variables (geometry.f90:14-18) -- for builds whose kx the
+        reference has no set for."""
+        arrs = [_f64(x) for x in (hsg, dhs, fsg, dhsr, fsgr)]
+        self.lib.ref_set_sigma(*[_ptr(x) for x in arrs])
+
+    def coriol(self):
+        o = np.zeros(self.il); self.lib.ref_get_coriol(_ptr(o)); return o
+
+    def corv(self):
+        a = np.zeros(self.kx); b = np.zeros(self.kx); self.lib.ref_get_corv(_ptr(a), _ptr(b))
+        return {"tcorv": a, "qcorv": b}
+
+    def geopotential(self, t, phis):
+        t = _c128(t); phis = _c128(phis); phi = np.empty_like(t)
+        self.lib.ref_geopotential(_ptr(t), _ptr(phis), _ptr(phi)); return phi
 
     def dmp_tables(self):
         t = [np.zeros((self.nx, self.mx)) for _ in range(6)]

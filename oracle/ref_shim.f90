@@ -303,3 +303,49 @@ subroutine ref_roundtrip_loop(nf, nrep, g_in, g_out) bind(C, name="ref_roundtrip
         end do
     end do
 end subroutine
+
+! geometry.f90:14-18: the sigma-level tables are public module data.  For a level count the reference has no set
+! for (geometry.f90:42-48 knows kx = 5, 7, 8; this build may be compiled with another kx), the test supplies them;
+! nothing of the reference is re-implemented here -- initialize_implicit / initialize_geopotential /
+! initialize_horizontal_diffusion then run unchanged on these values.
+subroutine ref_set_sigma(i_hsg, i_dhs, i_fsg, i_dhsr, i_fsgr) bind(C, name="ref_set_sigma")
+    use iso_c_binding
+    use params, only: kx
+    use geometry, only: hsg, dhs, fsg, dhsr, fsgr
+    real(c_double), intent(in) :: i_hsg(kx+1), i_dhs(kx), i_fsg(kx), i_dhsr(kx), i_fsgr(kx)
+    hsg = i_hsg
+    dhs = i_dhs
+    fsg = i_fsg
+    dhsr = i_dhsr
+    fsgr = i_fsgr
+end subroutine
+
+! geometry.f90:31 public coriol
+subroutine ref_get_coriol(o) bind(C, name="ref_get_coriol")
+    use iso_c_binding
+    use params, only: il
+    use geometry, only: coriol
+    real(c_double), intent(out) :: o(il)
+    o = coriol
+end subroutine
+
+! horizontal_diffusion.f90:27-28 public tcorv, qcorv (after ref_tail_init)
+subroutine ref_get_corv(o_tcorv, o_qcorv) bind(C, name="ref_get_corv")
+    use iso_c_binding
+    use params, only: kx
+    use horizontal_diffusion, only: tcorv, qcorv
+    real(c_double), intent(out) :: o_tcorv(kx), o_qcorv(kx)
+    o_tcorv = tcorv
+    o_qcorv = qcorv
+end subroutine
+
+! geopotential.f90:18 initialize_geopotential ; :33 get_geopotential
+subroutine ref_geopotential(t, phis, phi) bind(C, name="ref_geopotential")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use geopotential, only: initialize_geopotential, get_geopotential
+    complex(c_double_complex), intent(in) :: t(mx,nx,kx), phis(mx,nx)
+    complex(c_double_complex), intent(out) :: phi(mx,nx,kx)
+    call initialize_geopotential
+    phi = get_geopotential(t, phis)
+end subroutine

@@ -43,6 +43,9 @@ typedef struct orc_ctx {
     double *dmp, *dmpd, *dmps, *dmp1, *dmp1d, *dmp1s;
     double *tref, *tref1, *tref2, *tref3, *xc, *xd, *xj, *dhsx, *elz;
     int tail_ready;
+    /* geometry.f90:89 ; geopotential.f90:14-15 ; horizontal_diffusion.f90:27-28 */
+    double *coriol, *xgeop1, *xgeop2, *tcorv, *qcorv;
+    int sigma_ready;
 } orc_ctx;
 
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
@@ -55,6 +58,51 @@ static double akap_(void) { return (double)(2.0f / 7.0f); }
 static const double GAMMA_LAPSE = (double)6.0f;
 static const double THD = (double)2.4f, THDD = (double)2.4f, THDS = (double)12.0f;
 static const double ALPH = (double)0.5f;               /* params.f90:34 */
+static const double OMEGA = (double)7.292e-05f;        /* physical_constants.f90:17 */
+static const double HSCALE = (double)7.5f, HSHUM = (double)2.5f;   /* dynamical_constants.f90:13-14 */
+static const double P0 = (double)1.e+5f;               /* physical_constants.f90:21 */
+
+/* Functions of the half levels: geometry.f90:51-60, initialize_geopotential (geopotential.f90:18-31) and the
+ * vertical orographic-correction profiles of initialize_horizontal_diffusion (horizontal_diffusion.f90:68-82). */
+static void sigma_functions(orc_ctx *c)
+{
+    const int kx = c->kx;
+    const double rgas = akap_() * CP;
+    double rgam, qexp;
+    int k;
+    for (k = 0; k < kx; ++k) {                                         /* geometry.f90:51-54 */
+        c->dhs[k] = c->hsg[k + 1] - c->hsg[k];
+        c->fsg[k] = 0.5 * (c->hsg[k + 1] + c->hsg[k]);
+    }
+    for (k = 0; k < kx; ++k) {                                         /* :57-60 */
+        c->dhsr[k] = 0.5 / c->dhs[k];
+        c->fsgr[k] = akap_() / (2.0 * c->fsg[k]);
+    }
+    for (k = 1; k <= kx; ++k) {                                        /* geopotential.f90:26-29, 1-based k */
+        c->xgeop1[k - 1] = rgas * log(c->hsg[k] / c->fsg[k - 1]);
+        if (k != kx) c->xgeop2[k] = rgas * log(c->fsg[k] / c->hsg[k]);
+    }
+    rgam = rgas * GAMMA_LAPSE / (1000.0 * GRAV);                       /* horizontal_diffusion.f90:70-71 */
+    qexp = HSCALE / HSHUM;
+    c->tcorv[0] = 0.0;
+    c->qcorv[0] = 0.0;
+    if (kx > 1) c->qcorv[1] = 0.0;
+    for (k = 2; k <= kx; ++k) {                                        /* :77-80 */
+        c->tcorv[k - 1] = pow(c->fsg[k - 1], rgam);
+        if (k > 2) c->qcorv[k - 1] = pow(c->fsg[k - 1], qexp);
+    }
+    c->sigma_ready = 1;
+}
+
+/* Test hook for level counts the reference has no sigma set for (geometry.f90:42-48 knows kx = 5, 7, 8): the
+ * half levels are supplied, everything derived from them follows the reference recipes above.                 */
+ORC_API void orc_set_sigma(orc_ctx *c, const double *hsg)
+{
+    int k;
+    for (k = 0; k <= c->kx; ++k) c->hsg[k] = hsg[k];
+    sigma_functions(c);
+    c->tail_ready = 0;
+}
 
 /* ------------------------------------------------------------------ geometry.f90:35-89 */
 static void init_geometry(orc_ctx *c)
@@ -65,14 +113,7 @@ static void init_geometry(orc_ctx *c)
     const float *hs = c->kx == 8 ? hs8 : c->kx == 7 ? hs7 : c->kx == 5 ? hs5 : NULL;
     int k, j;
     for (k = 0; k <= c->kx; ++k) c->hsg[k] = hs ? (double)hs[k] : 0.0;   /* geometry.f90:42-48 [f32] */
-    for (k = 0; k < c->kx; ++k) {                                         /* :51-60 */
-        c->dhs[k] = c->hsg[k + 1] - c->hsg[k];
-        c->fsg[k] = 0.5 * (c->hsg[k + 1] + c->hsg[k]);
-    }
-    for (k = 0; k < c->kx; ++k) {
-        c->dhsr[k] = 0.5 / c->dhs[k];
-        c->fsgr[k] = akap_() / (2.0 * c->fsg[k]);
-    }
+    if (hs) sigma_functions(c);
     for (j = 1; j <= c->iy; ++j) {                                        /* :66-86 */
         int jj = c->il + 1 - j;
         /* whole right-hand side is default-real: float32 pi literal, float32 cos  [f32] */
@@ -83,6 +124,8 @@ static void init_geometry(orc_ctx *c)
         c->coa_half[j - 1] = co;      /* declared (il) but only 1..iy are ever set (geometry.f90:69) */
         c->cosgr[j - 1] = 1.0 / co;  c->cosgr[jj - 1] = 1.0 / co;
         c->cosgr2[j - 1] = 1.0 / (co * co);  c->cosgr2[jj - 1] = 1.0 / (co * co);
+        c->coriol[j - 1] = 2.0 * OMEGA * (-s);                            /* :70-71, :89: coriol = 2.0*omega*sia */
+        c->coriol[jj - 1] = 2.0 * OMEGA * s;
     }
 }
 
@@ -831,7 +874,7 @@ ORC_API int orc_tail_init(orc_ctx *c, double dt)
     double xi, xxi;
     int m, n, k, k1, k2, l, rc = 0;
 #define M2(a, r, cc_) a[(r) + kx * (cc_)]
-    if (kx != 5 && kx != 7 && kx != 8) return -2;      /* geometry.f90:42-48 defines no other sigma set */
+    if (!c->sigma_ready) return -2;                    /* geometry.f90:42-48 defines no sigma set for this kx (orc_set_sigma) */
     init_hdiff(c);
     for (m = 0; m < mx * nx; ++m) {
         c->dmp1[m] = 1.0 / (1.0 + c->dmp[m] * dt);
@@ -933,6 +976,112 @@ ORC_API void orc_implicit_terms(const orc_ctx *c, double *divdt, double *tdt, do
     free(ye); free(yf);
 }
 
+/* ------------------------------------------------------------------ geopotential.f90:33-57 */
+ORC_API void orc_geopotential(const orc_ctx *c, const double *t, const double *phis, double *phi)
+{
+    const int mx = c->mx, nx = c->nx, kx = c->kx, sz = mx * nx;
+    int k, i, n;
+    for (i = 0; i < sz; ++i)                                             /* 1. bottom layer (:45) */
+        cset(phi, (kx - 1) * sz + i, cadd(cget(phis, i), rmul(c->xgeop1[kx - 1], cget(t, (kx - 1) * sz + i))));
+    for (k = kx - 2; k >= 0; --k)                                        /* 2. other layers (:48-51) */
+        for (i = 0; i < sz; ++i)
+            cset(phi, k * sz + i, cadd(cadd(cget(phi, (k + 1) * sz + i), rmul(c->xgeop2[k + 1], cget(t, (k + 1) * sz + i))),
+                                       rmul(c->xgeop1[k], cget(t, k * sz + i))));
+    for (k = 1; k <= kx - 2; ++k) {                                      /* 3. lapse-rate correction, m = 1 only (:54-57) */
+        double corf = c->xgeop1[k] * 0.5 * log(c->hsg[k + 1] / c->fsg[k]) / log(c->fsg[k + 1] / c->fsg[k - 1]);
+        for (n = 0; n < nx; ++n)
+            cset(phi, k * sz + SI(0, n), cadd(cget(phi, k * sz + SI(0, n)),
+                                              rmul(corf, csub(cget(t, (k + 1) * sz + SI(0, n)), cget(t, (k - 1) * sz + SI(0, n))))));
+    }
+}
+
+/* ------------------------------------------------------------------ tendencies.f90:242-293 get_spectral_tendencies
+ * PARITY UNPINNED: tendencies.f90 cannot be compiled here (it uses prognostics -> boundaries/input_output -> netcdf),
+ * so this routine is a reading of the source that no reference build has confirmed.  (get_geopotential inside it IS
+ * pinned.)  div, t, ps: time level j2 of the prognostics.                                                           */
+ORC_API void orc_spectral_tendencies(const orc_ctx *c, const double *div, const double *t, const double *ps, const double *phis,
+                                     double *divdt, double *tdt, double *psdt, double *phi)
+{
+    const int mx = c->mx, nx = c->nx, kx = c->kx, sz = mx * nx;
+    const double rgas = akap_() * CP;
+    double *dmeanc = dalloc((size_t)2 * sz), *sigdtc = dalloc((size_t)2 * sz * (kx + 1)), *dumk = dalloc((size_t)2 * sz * (kx + 1));
+    int k, i;
+    for (k = 0; k < kx; ++k)                                             /* :257-260 */
+        for (i = 0; i < sz; ++i) cset(dmeanc, i, cadd(cget(dmeanc, i), rmul(c->dhs[k], cget(div, k * sz + i))));
+    for (i = 0; i < sz; ++i) cset(psdt, i, csub(cget(psdt, i), cget(dmeanc, i)));   /* :262 */
+    psdt[0] = 0.0; psdt[1] = 0.0;                                        /* :263 */
+    /* sigdtc(:,:,1) = sigdtc(:,:,kx+1) = 0 (calloc) ; :269-271 */
+    for (k = 0; k < kx - 1; ++k)
+        for (i = 0; i < sz; ++i)
+            cset(sigdtc, (k + 1) * sz + i, csub(cget(sigdtc, k * sz + i), rmul(c->dhs[k], csub(cget(div, k * sz + i), cget(dmeanc, i)))));
+    for (k = 1; k < kx; ++k)                                             /* :276-278 */
+        for (i = 0; i < sz; ++i) cset(dumk, k * sz + i, rmul(c->tref[k] - c->tref[k - 1], cget(sigdtc, k * sz + i)));
+    for (k = 0; k < kx; ++k)                                             /* :280-284 */
+        for (i = 0; i < sz; ++i) {
+            cplx a = csub(cget(tdt, k * sz + i), rmul(c->dhsr[k], cadd(cget(dumk, (k + 1) * sz + i), cget(dumk, k * sz + i))));
+            cplx b = cadd(a, rmul(c->tref3[k], cadd(cget(sigdtc, (k + 1) * sz + i), cget(sigdtc, k * sz + i))));
+            cset(tdt, k * sz + i, csub(b, rmul(c->tref2[k], cget(dmeanc, i))));
+        }
+    orc_geopotential(c, t, phis, phi);                                   /* :287 */
+    for (k = 0; k < kx; ++k)                                             /* :289-291: divdt - laplacian(phi + rgas*tref(k)*ps) */
+        for (i = 0; i < sz; ++i) {
+            cplx x = cadd(cget(phi, k * sz + i), rmul(rgas * c->tref[k], cget(ps, i)));
+            cset(divdt, k * sz + i, csub(cget(divdt, k * sz + i), rmul(c->el2[i], cneg(x))));
+        }
+    free(dmeanc); free(sigdtc); free(dumk);
+}
+
+/* ------------------------------------------------------------------ time_stepping.f90:62-96: the diffusion block of step()
+ * PARITY UNPINNED (time_stepping.f90 uses prognostics/tendencies -> netcdf chain; do_horizontal_diffusion itself is pinned).
+ * vor, div, t, tr: time level 1; tcorh, qcorh: (mx,nx) complex; tr/trdt may be NULL.                                */
+ORC_API void orc_hdiff_step(const orc_ctx *c, const double *vor, const double *div, const double *t, const double *tr,
+                            const double *tcorh, const double *qcorh, double sdrag,
+                            double *vordt, double *divdt, double *tdt, double *trdt)
+{
+    const int mx = c->mx, nx = c->nx, kx = c->kx, sz = mx * nx;
+    double *ctmp = dalloc((size_t)2 * sz * kx), *tmp = dalloc((size_t)2 * sz * kx);
+    int k, i, n;
+    orc_hdiff(c, kx, vor, vordt, c->dmp, c->dmp1, tmp);  memcpy(vordt, tmp, sizeof(double) * 2 * sz * kx);    /* :63 */
+    orc_hdiff(c, kx, div, divdt, c->dmpd, c->dmp1d, tmp); memcpy(divdt, tmp, sizeof(double) * 2 * sz * kx);   /* :64 */
+    for (k = 0; k < kx; ++k)                                                                                 /* :66-72 */
+        for (i = 0; i < sz; ++i) cset(ctmp, k * sz + i, cadd(cget(t, k * sz + i), rmul(c->tcorv[k], cget(tcorh, i))));
+    orc_hdiff(c, kx, ctmp, tdt, c->dmp, c->dmp1, tmp);   memcpy(tdt, tmp, sizeof(double) * 2 * sz * kx);      /* :74 */
+    for (n = 0; n < nx; ++n) {                                                                               /* :77-81 */
+        cset(vordt, SI(0, n), csub(cget(vordt, SI(0, n)), rmul(sdrag, cget(vor, SI(0, n)))));
+        cset(divdt, SI(0, n), csub(cget(divdt, SI(0, n)), rmul(sdrag, cget(div, SI(0, n)))));
+    }
+    orc_hdiff(c, kx, vor, vordt, c->dmps, c->dmp1s, tmp); memcpy(vordt, tmp, sizeof(double) * 2 * sz * kx);  /* :83-85 */
+    orc_hdiff(c, kx, div, divdt, c->dmps, c->dmp1s, tmp); memcpy(divdt, tmp, sizeof(double) * 2 * sz * kx);
+    orc_hdiff(c, kx, ctmp, tdt, c->dmps, c->dmp1s, tmp);  memcpy(tdt, tmp, sizeof(double) * 2 * sz * kx);
+    if (tr) {
+        for (k = 0; k < kx; ++k)                                                                             /* :88-94 */
+            for (i = 0; i < sz; ++i) cset(ctmp, k * sz + i, cadd(cget(tr, k * sz + i), rmul(c->qcorv[k], cget(qcorh, i))));
+        orc_hdiff(c, kx, ctmp, trdt, c->dmpd, c->dmp1d, tmp); memcpy(trdt, tmp, sizeof(double) * 2 * sz * kx);   /* :96 */
+    }
+    free(ctmp); free(tmp);
+}
+
+/* ------------------------------------------------------------------ time_stepping.f90:121-167 step_field_2d / _3d
+ * PARITY UNPINNED (see above).  field(mx,nx,nlev,2): both time levels; fdt(mx,nx,nlev) truncated in place (:155-157). */
+ORC_API void orc_step_field(const orc_ctx *c, int nlev, int j1, double dt, double eps, double wil, double *field, double *fdt)
+{
+    const int sz = c->mx * c->nx;
+    double *l1 = field, *l2 = field + (size_t)2 * sz * nlev, *lj = (j1 == 1) ? l1 : l2;
+    double *fnew = dalloc((size_t)2 * sz);
+    int k, i;
+    for (k = 0; k < nlev; ++k) {
+        if (c->ix == c->iy * 4) orc_trunct(c, fdt + (size_t)2 * sz * k);
+        for (i = 0; i < sz; ++i) cset(fnew, i, cadd(cget(l1, k * sz + i), rmul(dt, cget(fdt, k * sz + i))));       /* :160 */
+        for (i = 0; i < sz; ++i)                                                                                   /* :161 */
+            cset(l1, k * sz + i, cadd(cget(lj, k * sz + i),
+                                      rmul(wil * eps, cadd(csub(cget(l1, k * sz + i), rmul(2.0, cget(lj, k * sz + i))), cget(fnew, i)))));
+        for (i = 0; i < sz; ++i)                                                                                   /* :164 */
+            cset(l2, k * sz + i, csub(cget(fnew, i),
+                                      rmul((1.0 - wil) * eps, cadd(csub(cget(l1, k * sz + i), rmul(2.0, cget(lj, k * sz + i))), cget(fnew, i)))));
+    }
+    free(fnew);
+}
+
 /* ------------------------------------------------------------------ context */
 ORC_API orc_ctx *orc_create(int trunc, int ix, int iy, int kx)
 {
@@ -955,6 +1104,7 @@ ORC_API orc_ctx *orc_create(int trunc, int ix, int iy, int kx)
     c->tref = dalloc(kx); c->tref1 = dalloc(kx); c->tref2 = dalloc(kx); c->tref3 = dalloc(kx);
     c->xc = dalloc((size_t)kx * kx); c->xd = dalloc((size_t)kx * kx);
     c->xj = dalloc((size_t)kx * kx * (mx + nx + 1)); c->dhsx = dalloc(kx); c->elz = dalloc(t);
+    c->coriol = dalloc(c->il); c->xgeop1 = dalloc(kx); c->xgeop2 = dalloc(kx); c->tcorv = dalloc(kx); c->qcorv = dalloc(kx);
     init_geometry(c);
     orc_rffti1(ix, c->work, c->ifac);
     init_legendre(c);
@@ -974,6 +1124,7 @@ ORC_API void orc_destroy(orc_ctx *c)
     free(c->dmp); free(c->dmpd); free(c->dmps); free(c->dmp1); free(c->dmp1d); free(c->dmp1s);
     free(c->tref); free(c->tref1); free(c->tref2); free(c->tref3);
     free(c->xc); free(c->xd); free(c->xj); free(c->dhsx); free(c->elz);
+    free(c->coriol); free(c->xgeop1); free(c->xgeop2); free(c->tcorv); free(c->qcorv);
     free(c);
 }
 
@@ -999,6 +1150,8 @@ ORC_API int orc_get_table(const orc_ctx *c, const char *name, double *out)
     TBL("tref", c->tref, kx) TBL("tref1", c->tref1, kx) TBL("tref2", c->tref2, kx) TBL("tref3", c->tref3, kx)
     TBL("xc", c->xc, kx * kx) TBL("xd", c->xd, kx * kx) TBL("xj", c->xj, kx * kx * (mx + nx + 1))
     TBL("dhsx", c->dhsx, kx) TBL("elz", c->elz, t)
+    TBL("coriol", c->coriol, c->il) TBL("xgeop1", c->xgeop1, kx) TBL("xgeop2", c->xgeop2, kx)
+    TBL("tcorv", c->tcorv, kx) TBL("qcorv", c->qcorv, kx)
     if (!strcmp(name, "ifac")) { for (i = 0; i < 15; ++i) out[i] = (double)c->ifac[i]; return 15; }
     if (!strcmp(name, "nsh2")) { for (i = 0; i < nx; ++i) out[i] = (double)c->nsh2[i]; return nx; }
     if (!src) return -1;

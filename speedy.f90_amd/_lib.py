@@ -60,6 +60,19 @@ SIGNATURES = {
     "spdy_hdiff_multi_dev": [c_void_p, c_int, c_void_p],
     "spdy_direct_batch_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "spdy_inverse_batch_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "spdy_plan_set_sigma": [c_void_p, c_void_p],
+    "spdy_geopotential": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_geopotential_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_spectral_tendencies_dev": [c_void_p] * 9,
+    "spdy_hdiff_step_dev": [c_void_p] * 7 + [c_double] + [c_void_p] * 4,
+    "spdy_step_fields_dev": [c_void_p, c_int, c_void_p, c_int, c_double, c_double, c_double],
+    "spdy_step_field": [c_void_p, c_int, c_int, c_double, c_double, c_double, c_void_p, c_void_p],
+    "spdy_comm_unique_id": [c_void_p],
+    "spdy_comm_create": [c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)],
+    "spdy_comm_destroy": [c_void_p],
+    "spdy_comm_level_range": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
+    "spdy_allgather_levels_dev": [c_void_p, c_int, c_int, c_void_p],
+    "spdy_implicit_terms_sharded_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
     "spdy_graph_begin": [c_void_p],
     "spdy_graph_end": [c_void_p, ctypes.POINTER(c_void_p)],
     "spdy_graph_launch": [c_void_p],

@@ -10,46 +10,17 @@
 #include <string>
 #include <vector>
 
-#include "../../include/spdy.h"
-#include "spdy_kernels.hpp"
-#include "spdy_tables.hpp"
+#include "spdy_plan.hpp"
 
 using spdy::DevPlan;
 using spdy::HostTables;
-
-struct spdy_graph {
-    struct spdy_plan *plan = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-};
-
-struct spdy_plan {
-    HostTables tab;
-    int max_batch = 0;
-    int device = -1;
-    DevPlan dev{};
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    std::vector<void *> allocs;       // everything hipMalloc'ed for this plan
-    double *four = nullptr;           // [max_batch][il][fs] Fourier workspace
-    double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;  // host-API staging
-    size_t stage_elems = 0;
-    int *d_kcos = nullptr;
-    // device copies of dt-dependent tables
-    double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
-    int num_cu = 256;
-    int wg_per_cu = 1;                // fused kernels: one 448-thread wave-specialised workgroup per CU
-    int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
-    // optional per-kernel timing (HIP events on the launch stream)
-    bool profiling = false;
-    bool capturing = false;           // between spdy_graph_begin and spdy_graph_end
-    struct Span { int kind; hipEvent_t t0, t1; };
-    std::vector<Span> spans;
-};
+using namespace spdy_detail;
 
 namespace {
-
 thread_local std::string g_err;
+}
+
+namespace spdy_detail {
 
 int fail(int code, const char *fmt, ...)
 {
@@ -62,23 +33,6 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                             \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) return fail(SPDY_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-#define NEED_PLAN(p)                                                                   \
-    do {                                                                               \
-        if (!(p)) return fail(SPDY_ERR_ARG, "null plan");                              \
-    } while (0)
-#define NEED_DEVICE(p)                                                                                       \
-    do {                                                                                                     \
-        NEED_PLAN(p);                                                                                        \
-        if ((p)->device < 0) return fail(SPDY_ERR_NO_DEVICE, "host-only plan: no HIP device, no CPU fallback"); \
-        HIP_TRY(hipSetDevice((p)->device));                                                                  \
-    } while (0)
-
 int dev_alloc(spdy_plan *p, size_t bytes, void **out)
 {
     void *ptr = nullptr;
@@ -87,6 +41,10 @@ int dev_alloc(spdy_plan *p, size_t bytes, void **out)
     *out = ptr;
     return SPDY_OK;
 }
+
+}  // namespace spdy_detail
+
+namespace {
 
 int dev_upload(spdy_plan *p, const std::vector<double> &v, const double **out)
 {
@@ -161,16 +119,21 @@ int upload_all(spdy_plan *p)
     HostTables &t = p->tab;
     DevPlan &d = p->dev;
     d.trunc = t.trunc; d.ix = t.ix; d.iy = t.iy; d.il = t.il; d.kx = t.kx; d.nx = t.nx; d.mx = t.mx;
+    d.num_cu = p->num_cu;
     d.fs = (2 * t.mx + 15) / 16 * 16;
     d.ks_inv = ((t.nx + 1) / 2 + 3) / 4;
     d.jt = (t.iy + 15) / 16;
     d.nt_dir = ((t.nx + 1) / 2 + 15) / 16;
     d.js_dir = t.iy / 4;
+    d.rgas = t.rgas;
+    d.akap = t.akap;
+    HIP_TRY(spdy::prepare_device_kernels());
+    HIP_TRY(spdy::prepare_device_step_kernels(t.kx));
     std::vector<double> inv, dir;
     build_mfma_tables(t, d.ks_inv, d.jt, d.nt_dir, d.js_dir, inv, dir);
     int rc;
 #define UP(vec, field) if ((rc = dev_upload(p, vec, &d.field))) return rc
-    UP(inv, pa_inv); UP(dir, pa_dir); UP(t.cosgr, cosgr); UP(t.cosgr2, cosgr2);
+    UP(inv, pa_inv); UP(dir, pa_dir); UP(t.cosgr, cosgr); UP(t.cosgr2, cosgr2); UP(t.coriol, coriol);
     d.pa_inv2 = d.pa_dir2 = d.img_s2g = d.img_g2s = nullptr;
     if (t.trunc == 30) {
         std::vector<double> inv2, dir2;
@@ -217,18 +180,10 @@ int upload_all(spdy_plan *p)
     fc.taui = t.taui; fc.sqrt2 = t.sqrt2; fc.hsqt2 = t.hsqt2; fc.scale = t.fwd_scale;
     HIP_TRY(spdy::upload_fft_constants(t.ix, fc));
 
-    const size_t four_elems = (size_t)p->max_batch * t.il * d.fs;
     void *ptr;
-    if ((rc = dev_alloc(p, four_elems * sizeof(double), &ptr))) return rc;
-    p->four = static_cast<double *>(ptr);
-    HIP_TRY(hipMemset(p->four, 0, four_elems * sizeof(double)));
-    // staging for the host-pointer API: four buffers big enough for max_batch grids (the largest array kind)
-    p->stage_elems = (size_t)p->max_batch * t.il * t.ix;
-    double **stages[4] = {&p->stage_a, &p->stage_b, &p->stage_c, &p->stage_d};
-    for (auto s : stages) {
-        if ((rc = dev_alloc(p, p->stage_elems * sizeof(double), &ptr))) return rc;
-        *s = static_cast<double *>(ptr);
-    }
+    // the Fourier workspace and the host-API staging buffers are allocated on demand (ensure_four / ensure_staging):
+    // a device-resident T30 host needs neither (at the bench configuration they would be 1 GB)
+    if (t.trunc != 30 || p->fused_mode == 0) RC(ensure_four(p));
     if ((rc = dev_alloc(p, sizeof(int) * (size_t)p->max_batch, &ptr))) return rc;
     p->d_kcos = static_cast<int *>(ptr);
     for (int i = 0; i < 6; ++i) {
@@ -239,21 +194,76 @@ int upload_all(spdy_plan *p)
     for (int i = 0; i < 3; ++i)
         HIP_TRY(hipMemcpy(p->d_dmp[i], src[i]->data(), sizeof(double) * t.mx * t.nx, hipMemcpyHostToDevice));
     const int kx = t.kx;
-    struct { double **dst; size_t n; } imp[6] = {{&p->d_xd, (size_t)kx * kx}, {&p->d_xc, (size_t)kx * kx},
+    struct { double **dst; size_t n; } imp[7] = {{&p->d_xd, (size_t)kx * kx}, {&p->d_xc, (size_t)kx * kx},
                                                  {&p->d_xj, (size_t)kx * kx * (t.mx + t.nx + 1)},
                                                  {&p->d_tref1, (size_t)kx}, {&p->d_dhsx, (size_t)kx},
-                                                 {&p->d_elz, (size_t)t.mx * t.nx}};
+                                                 {&p->d_elz, (size_t)t.mx * t.nx},
+                                                 {&p->d_levtab, (size_t)spdy::LEVTAB_COUNT * kx}};
     for (auto &e : imp) {
         if ((rc = dev_alloc(p, e.n * sizeof(double), &ptr))) return rc;
         *e.dst = static_cast<double *>(ptr);
     }
     d.xd = p->d_xd; d.xc = p->d_xc; d.xj = p->d_xj; d.tref1 = p->d_tref1; d.dhsx = p->d_dhsx; d.elz = p->d_elz;
+    const double *lt = p->d_levtab;
+    d.dhs = lt; d.dhsr = lt + kx; d.fsgr = lt + 2 * kx; d.tref = lt + 3 * kx; d.tref2 = lt + 4 * kx; d.tref3 = lt + 5 * kx;
+    d.rgtref = lt + 6 * kx; d.xgeop1 = lt + 7 * kx; d.xgeop2 = lt + 8 * kx; d.corf = lt + 9 * kx; d.tcorv = lt + 10 * kx;
+    d.qcorv = lt + 11 * kx;
+    return upload_level_tables(p);
+}
+
+}  // namespace
+
+namespace spdy_detail {
+
+// Per-level tables in DevPlan order.  Sigma-level functions are valid once sigma levels exist, tref* once
+// spdy_implicit_init ran (zeros before).
+int upload_level_tables(spdy_plan *p)
+{
+    if (p->device < 0) return SPDY_OK;
+    const HostTables &t = p->tab;
+    const int kx = t.kx;
+    std::vector<double> h((size_t)spdy::LEVTAB_COUNT * kx, 0.0);
+    auto put = [&](int slot, const std::vector<double> &v) {
+        for (int k = 0; k < kx && k < (int)v.size(); ++k) h[(size_t)slot * kx + k] = v[k];
+    };
+    put(0, t.dhs); put(1, t.dhsr); put(2, t.fsgr); put(3, t.tref); put(4, t.tref2); put(5, t.tref3);
+    for (int k = 0; k < kx && k < (int)t.tref.size(); ++k) h[(size_t)6 * kx + k] = t.rgas * t.tref[k];
+    put(7, t.xgeop1); put(8, t.xgeop2); put(9, t.corf); put(10, t.tcorv); put(11, t.qcorv);
+    HIP_TRY(hipMemcpy(p->d_levtab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     return SPDY_OK;
 }
 
-inline size_t spec_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.nx; }
-inline size_t grid_elems(const spdy_plan *p) { return (size_t)p->tab.ix * p->tab.il; }
-inline size_t four_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.il; }
+int ensure_four(spdy_plan *p)
+{
+    if (p->four) return SPDY_OK;
+    NOT_CAPTURING(p, "allocating the Fourier workspace (call spdy_plan_set_fused / one transform before the capture)");
+    const size_t n = (size_t)p->max_batch * p->tab.il * p->dev.fs;
+    void *ptr;
+    RC(dev_alloc(p, n * sizeof(double), &ptr));
+    p->four = static_cast<double *>(ptr);
+    HIP_TRY(hipMemset(p->four, 0, n * sizeof(double)));
+    // two spectral temporaries for the operator + transform sequences (uvspec/grad -> grid, grid -> vds)
+    for (double **t : {&p->tmp_c, &p->tmp_d}) {
+        RC(dev_alloc(p, (size_t)p->max_batch * spec_elems(p) * sizeof(double), &ptr));
+        *t = static_cast<double *>(ptr);
+    }
+    return SPDY_OK;
+}
+
+int ensure_staging(spdy_plan *p)
+{
+    if (p->stage_a) return SPDY_OK;
+    NOT_CAPTURING(p, "a host-pointer entry point");
+    // four buffers big enough for max_batch grids (the largest array kind)
+    p->stage_elems = (size_t)p->max_batch * p->tab.il * p->tab.ix;
+    double **stages[4] = {&p->stage_a, &p->stage_b, &p->stage_c, &p->stage_d};
+    void *ptr;
+    for (auto s : stages) {
+        RC(dev_alloc(p, p->stage_elems * sizeof(double), &ptr));
+        *s = static_cast<double *>(ptr);
+    }
+    return SPDY_OK;
+}
 
 int check_batch(const spdy_plan *p, int nb)
 {
@@ -263,19 +273,31 @@ int check_batch(const spdy_plan *p, int nb)
 
 int h2d(spdy_plan *p, double *dst, const double *src, size_t n)
 {
-    if (p->capturing) return fail(SPDY_ERR_STATE, "host-pointer entry points cannot be captured into a graph");
+    NOT_CAPTURING(p, "a host-pointer entry point");
     if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
     return SPDY_OK;
 }
 int d2h(spdy_plan *p, double *dst, const double *src, size_t n)
 {
-    if (p->capturing) return fail(SPDY_ERR_STATE, "host-pointer entry points cannot be captured into a graph");
+    NOT_CAPTURING(p, "a host-pointer entry point");
     if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     return SPDY_OK;
 }
+int sync(spdy_plan *p)
+{
+    NOT_CAPTURING(p, "synchronising");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SPDY_OK;
+}
+
+}  // namespace spdy_detail
+
+namespace {
+
 // Fourier workspace rows are fs doubles apart; the reference layout packs 2*mx per row.
 int four_to_host(spdy_plan *p, double *dst, int nb)
 {
+    NOT_CAPTURING(p, "a host-pointer entry point");
     const size_t w = 2 * (size_t)p->tab.mx * sizeof(double);
     if (nb) HIP_TRY(hipMemcpy2DAsync(dst, w, p->four, p->dev.fs * sizeof(double), w, (size_t)nb * p->tab.il,
                                      hipMemcpyDeviceToHost, p->stream));
@@ -283,20 +305,12 @@ int four_to_host(spdy_plan *p, double *dst, int nb)
 }
 int four_from_host(spdy_plan *p, const double *src, int nb)
 {
+    NOT_CAPTURING(p, "a host-pointer entry point");
     const size_t w = 2 * (size_t)p->tab.mx * sizeof(double);
     if (nb) HIP_TRY(hipMemcpy2DAsync(p->four, p->dev.fs * sizeof(double), src, w, w, (size_t)nb * p->tab.il,
                                      hipMemcpyHostToDevice, p->stream));
     return SPDY_OK;
 }
-int sync(spdy_plan *p)
-{
-    if (p->capturing) return fail(SPDY_ERR_STATE, "cannot synchronise while a graph capture is open");
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    return SPDY_OK;
-}
-
-#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
-#define KERNEL(expr) HIP_TRY(expr)
 
 // Launch one transform kernel; when profiling is on, bracket it with HIP events recorded on
 // the very stream it runs on (kind: SPDY_K_*).
@@ -336,7 +350,7 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
     if (!((trunc == 30 && ix == 96 && iy == 24) || (trunc == 63 && ix == 192 && iy == 48)))
         return fail(SPDY_ERR_UNSUPPORTED, "kernels are built for T30 (96x48) and T63 (192x96); got trunc=%d ix=%d iy=%d",
                     trunc, ix, iy);
-    if (kx < 1 || kx > 8) return fail(SPDY_ERR_UNSUPPORTED, "kx=%d outside 1..8", kx);
+    if (kx < 1 || kx > SPDY_MAX_KX) return fail(SPDY_ERR_UNSUPPORTED, "kx=%d outside 1..%d", kx, (int)SPDY_MAX_KX);
     spdy_plan *p = new spdy_plan;
     const std::string err = p->tab.build(trunc, ix, iy, kx);
     if (!err.empty()) {
@@ -344,6 +358,20 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
         return fail(SPDY_ERR_TABLE, "table generation: %s", err.c_str());
     }
     p->max_batch = max_batch;
+    if (device == SPDY_DEVICE_AUTO) {
+        // one process per GPU: $SPDY_DEVICE wins, else the launcher's local rank modulo the visible devices
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+        device = 0;
+        if (const char *env = getenv("SPDY_DEVICE")) device = atoi(env);
+        else
+            for (const char *name : {"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "MPI_LOCALRANKID"})
+                if (const char *v = getenv(name)) { device = atoi(v) % ndev; break; }
+        if (device < 0) device = 0;
+    } else if (device < SPDY_DEVICE_AUTO) {
+        delete p;
+        return fail(SPDY_ERR_ARG, "device=%d: use a device index, SPDY_DEVICE_AUTO or SPDY_DEVICE_NONE", device);
+    }
     p->device = device;
     if (device >= 0) {
         int ndev = 0;
@@ -379,8 +407,17 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
 int spdy_plan_destroy(spdy_plan *p)
 {
     if (!p) return SPDY_OK;
+    // graphs captured from this plan point at its workspaces and tables: they die with it (spdy_graph_launch then
+    // returns SPDY_ERR_STATE; spdy_graph_destroy still frees the handle)
+    for (spdy_graph *g : p->graphs) {
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        g->exec = nullptr; g->graph = nullptr; g->plan = nullptr;
+    }
+    p->graphs.clear();
     if (p->device >= 0) {
         (void)hipSetDevice(p->device);
+        if (p->capturing) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(p->stream, &dead); if (dead) (void)hipGraphDestroy(dead); }
         if (p->stream) (void)hipStreamSynchronize(p->stream);
         for (void *a : p->allocs) (void)hipFree(a);
         if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
@@ -414,6 +451,10 @@ int spdy_plan_set_fused(spdy_plan *p, int mode)
 {
     NEED_PLAN(p);
     if (mode < -1 || mode > 1) return fail(SPDY_ERR_ARG, "fused mode must be -1, 0 or 1");
+    if (mode == 0 && p->device >= 0) {
+        HIP_TRY(hipSetDevice(p->device));
+        RC(ensure_four(p));
+    }
     p->fused_mode = mode;
     return SPDY_OK;
 }
@@ -455,7 +496,7 @@ int spdy_get_table(const spdy_plan *p, const char *name, double *buf, int cap)
     int n = 0;
     const double *src = p->tab.lookup(name, &n, scratch);
     if (!src) return fail(SPDY_ERR_ARG, "unknown table '%s'", name);
-    if (buf) std::memcpy(buf, src, sizeof(double) * (size_t)(n < cap ? n : cap));
+    if (buf && cap > 0) std::memcpy(buf, src, sizeof(double) * (size_t)(n < cap ? n : cap));
     return n;
 }
 
@@ -469,6 +510,7 @@ int spdy_spec_to_grid_dev(spdy_plan *p, int nb, const double *d_spec, const int 
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu * p->wg_per_cu, p->stream);
         });
+    RC(ensure_four(p));
     RC(timed(p, SPDY_K_LEGENDRE_INV, [&] { return spdy::launch_legendre_inv(p->dev, nb, d_spec, p->four, p->stream); }));
     RC(timed(p, SPDY_K_FOURIER_INV, [&] { return spdy::launch_fourier_inv(p->dev, nb, p->four, d_kcos, kcos_all, d_grid, p->stream); }));
     return SPDY_OK;
@@ -483,6 +525,7 @@ int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_
         return timed(p, SPDY_K_G2S_FUSED, [&] {
             return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu * p->wg_per_cu, p->stream);
         });
+    RC(ensure_four(p));
     RC(timed(p, SPDY_K_FOURIER_DIR, [&] { return spdy::launch_fourier_dir(p->dev, nb, d_grid, nullptr, p->four, p->stream); }));
     RC(timed(p, SPDY_K_LEGENDRE_DIR, [&] { return spdy::launch_legendre_dir(p->dev, nb, p->four, d_spec, p->stream); }));
     return SPDY_OK;
@@ -493,6 +536,7 @@ int spdy_spec_to_grid_batch(spdy_plan *p, int nb, const double *spec, const int 
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    RC(ensure_staging(p));
     if (nb && (!spec || !grid)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, spec, nb * spec_elems(p)));
     if (kcos && nb) HIP_TRY(hipMemcpyAsync(p->d_kcos, kcos, sizeof(int) * nb, hipMemcpyHostToDevice, p->stream));
@@ -505,6 +549,7 @@ int spdy_grid_to_spec_batch(spdy_plan *p, int nb, const double *grid, double *sp
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    RC(ensure_staging(p));
     if (nb && (!spec || !grid)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, grid, nb * grid_elems(p)));
     RC(spdy_grid_to_spec_dev(p, nb, p->stage_a, p->stage_b));
@@ -527,6 +572,8 @@ int spdy_legendre_inv(spdy_plan *p, int nb, const double *spec, double *four)
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    RC(ensure_staging(p));
+    RC(ensure_four(p));
     if (nb && (!spec || !four)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, spec, nb * spec_elems(p)));
     KERNEL(spdy::launch_legendre_inv(p->dev, nb, p->stage_a, p->four, p->stream));
@@ -540,6 +587,8 @@ int spdy_legendre_dir(spdy_plan *p, int nb, const double *four, double *spec)
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    RC(ensure_staging(p));
+    RC(ensure_four(p));
     if (nb && (!spec || !four)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(four_from_host(p, four, nb));
     KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_a, p->stream));
@@ -551,6 +600,8 @@ int spdy_fourier_inv(spdy_plan *p, int nb, const double *four, int kcos, double 
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    RC(ensure_staging(p));
+    RC(ensure_four(p));
     if (nb && (!grid || !four)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(four_from_host(p, four, nb));
     KERNEL(spdy::launch_fourier_inv(p->dev, nb, p->four, nullptr, kcos, p->stage_a, p->stream));
@@ -562,6 +613,8 @@ int spdy_fourier_dir(spdy_plan *p, int nb, const double *grid, double *four)
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
+    RC(ensure_staging(p));
+    RC(ensure_four(p));
     if (nb && (!grid || !four)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, grid, nb * grid_elems(p)));
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, p->stage_a, nullptr, p->four, p->stream));
@@ -607,21 +660,25 @@ int spdy_uvspec_dev(spdy_plan *p, int nb, const double *vor, const double *dv, d
     return SPDY_OK;
 }
 /* uvspec / grad followed by the two inverse transforms their callers always do, in one pass where the fused
- * kernels exist; otherwise the operator kernel into stage_c/stage_d and two ordinary transforms.             */
+ * kernels exist; otherwise the operator kernel into plan-owned temporaries and two ordinary transforms.      */
 static int derived_to_grid(spdy_plan *p, int nb, int mode, const double *in0, const double *in1, double *g0, double *g1, int kcos)
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!in0 || (mode == 1 && !in1) || !g0 || !g1)) return fail(SPDY_ERR_ARG, "null device pointer");
-    if (kcos != 1 && kcos != 2) return fail(SPDY_ERR_ARG, "kcos must be 1 or 2");
+    kcos = kcos == 1 ? 1 : 2;   // fourier.f90:47-51: anything but 1 means "times cosgr"
     if (use_fused(p, nb))
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused(p->dev, nb, in0, nullptr, kcos, g0, p->num_cu * p->wg_per_cu, p->stream, mode, in1, g1);
         });
-    if (mode == 1) KERNEL(spdy::launch_uvspec(p->dev, nb, in0, in1, p->stage_c, p->stage_d, p->stream));
-    else KERNEL(spdy::launch_grad(p->dev, nb, in0, p->stage_c, p->stage_d, p->stream));
-    RC(spdy_spec_to_grid_dev(p, nb, p->stage_c, nullptr, kcos, g0));
-    RC(spdy_spec_to_grid_dev(p, nb, p->stage_d, nullptr, kcos, g1));
+    RC(ensure_four(p));
+    if (mode == 1) KERNEL(spdy::launch_uvspec(p->dev, nb, in0, in1, p->tmp_c, p->tmp_d, p->stream));
+    else {
+        // rows of psdy that grad leaves untouched (l > trunc+1 inside row nx) are never read by the transform
+        KERNEL(spdy::launch_grad(p->dev, nb, in0, p->tmp_c, p->tmp_d, p->stream));
+    }
+    RC(spdy_spec_to_grid_dev(p, nb, p->tmp_c, nullptr, kcos, g0));
+    RC(spdy_spec_to_grid_dev(p, nb, p->tmp_d, nullptr, kcos, g1));
     return SPDY_OK;
 }
 int spdy_uvspec_to_grid_dev(spdy_plan *p, int nb, const double *vor, const double *dv, double *ug, double *vg, int kcos)
@@ -633,26 +690,18 @@ int spdy_grad_to_grid_dev(spdy_plan *p, int nb, const double *psi, double *gx, d
     return derived_to_grid(p, nb, 2, psi, nullptr, gx, gy, kcos);
 }
 
-/* host-pointer forms (level stacks of the Fortran host): inputs to stage_a/b, grids come back from stage_c/d --
- * or, where the multi-kernel path keeps its intermediate spectra in stage_c/d, from stage_a/b               */
+/* host-pointer forms (level stacks of the Fortran host): inputs to stage_a/b, grids come back from stage_c/d */
 static int derived_to_grid_host(spdy_plan *p, int nb, int mode, const double *in0, const double *in1, double *g0, double *g1, int kcos)
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!in0 || (mode == 1 && !in1) || !g0 || !g1)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
     RC(h2d(p, p->stage_a, in0, nb * spec_elems(p)));
     if (mode == 1) RC(h2d(p, p->stage_b, in1, nb * spec_elems(p)));
-    const bool one_pass = use_fused(p, nb);
-    double *o0 = one_pass ? p->stage_c : p->stage_a, *o1 = one_pass ? p->stage_d : p->stage_b;
-    if (one_pass) RC(derived_to_grid(p, nb, mode, p->stage_a, p->stage_b, o0, o1, kcos));
-    else {
-        if (mode == 1) KERNEL(spdy::launch_uvspec(p->dev, nb, p->stage_a, p->stage_b, p->stage_c, p->stage_d, p->stream));
-        else KERNEL(spdy::launch_grad(p->dev, nb, p->stage_a, p->stage_c, p->stage_d, p->stream));
-        RC(spdy_spec_to_grid_dev(p, nb, p->stage_c, nullptr, kcos, o0));
-        RC(spdy_spec_to_grid_dev(p, nb, p->stage_d, nullptr, kcos, o1));
-    }
-    RC(d2h(p, g0, o0, nb * grid_elems(p)));
-    RC(d2h(p, g1, o1, nb * grid_elems(p)));
+    RC(derived_to_grid(p, nb, mode, p->stage_a, p->stage_b, p->stage_c, p->stage_d, kcos));
+    RC(d2h(p, g0, p->stage_c, nb * grid_elems(p)));
+    RC(d2h(p, g1, p->stage_d, nb * grid_elems(p)));
     return sync(p);
 }
 int spdy_uvspec_to_grid(spdy_plan *p, int nb, const double *vor, const double *dv, double *ug, double *vg, int kcos)
@@ -664,8 +713,8 @@ int spdy_grad_to_grid(spdy_plan *p, int nb, const double *psi, double *gx, doubl
     return derived_to_grid_host(p, nb, 2, psi, nullptr, gx, gy, kcos);
 }
 
-/* vdspec: scale on load, two direct transforms, then vds.  Uses stage_c/stage_d as the two
- * intermediate spectra, so ug/vg/vorm/divm may be the caller's own device buffers.            */
+/* vdspec: scale on load, two direct transforms, then vds.  The multi-kernel path keeps the two intermediate
+ * spectra in plan-owned temporaries, so ug/vg/vorm/divm may be the caller's own device buffers.       */
 int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, double *vorm, double *divm, int kcos)
 {
     NEED_DEVICE(p);
@@ -677,11 +726,12 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
         KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
         return SPDY_OK;
     }
+    RC(ensure_four(p));
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, ug, sc, p->four, p->stream));
-    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_c, p->stream));
+    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->tmp_c, p->stream));
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, vg, sc, p->four, p->stream));
-    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->stage_d, p->stream));
-    KERNEL(spdy::launch_vds(p->dev, nb, p->stage_c, p->stage_d, vorm, divm, p->stream));
+    KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->tmp_d, p->stream));
+    KERNEL(spdy::launch_vds(p->dev, nb, p->tmp_c, p->tmp_d, vorm, divm, p->stream));
     return SPDY_OK;
 }
 
@@ -692,7 +742,7 @@ int spdy_inverse_batch_dev(spdy_plan *p, int npairs, const double *vor, const do
     RC(check_batch(p, npairs));
     RC(check_batch(p, nplain));
     if ((npairs && (!vor || !dv || !ug || !vg)) || (nplain && (!spec || !grid))) return fail(SPDY_ERR_ARG, "null device pointer");
-    if (kcos_pairs != 1 && kcos_pairs != 2) return fail(SPDY_ERR_ARG, "kcos must be 1 or 2");
+    kcos_pairs = kcos_pairs == 1 ? 1 : 2;
     if (use_fused(p, npairs) && npairs > 0 && nplain > 0)
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused(p->dev, npairs, vor, nullptr, kcos_pairs, ug, p->num_cu * p->wg_per_cu, p->stream, 3, dv, vg,
@@ -727,6 +777,7 @@ int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const doub
         NEED_DEVICE(p);                                                            \
         RC(check_batch(p, nb));                                                    \
         if (nb && (!in || !out)) return fail(SPDY_ERR_ARG, "null pointer");        \
+        RC(ensure_staging(p));                                                     \
         RC(h2d(p, p->stage_a, in, nb * spec_elems(p)));                            \
         RC(devfn(p, nb, p->stage_a, p->stage_b));                                  \
         RC(d2h(p, out, p->stage_b, nb * spec_elems(p)));                           \
@@ -740,6 +791,7 @@ int spdy_trunct(spdy_plan *p, int nb, double *inout)
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && !inout) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
     RC(h2d(p, p->stage_a, inout, nb * spec_elems(p)));
     RC(spdy_trunct_dev(p, nb, p->stage_a));
     RC(d2h(p, inout, p->stage_a, nb * spec_elems(p)));
@@ -751,6 +803,7 @@ int spdy_grad(spdy_plan *p, int nb, const double *psi, double *psdx, double *psd
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!psi || !psdx || !psdy)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
     const size_t n = nb * spec_elems(p);
     RC(h2d(p, p->stage_a, psi, n));
     // rows of psdy the reference leaves untouched keep the caller's values
@@ -767,6 +820,7 @@ int spdy_grad(spdy_plan *p, int nb, const double *psi, double *psdx, double *psd
         NEED_DEVICE(p);                                                                              \
         RC(check_batch(p, nb));                                                                      \
         if (nb && (!a || !b || !c || !d)) return fail(SPDY_ERR_ARG, "null pointer");                 \
+        RC(ensure_staging(p));                                                                       \
         const size_t n = nb * spec_elems(p);                                                         \
         RC(h2d(p, p->stage_a, a, n));                                                                \
         RC(h2d(p, p->stage_b, b, n));                                                                \
@@ -785,116 +839,14 @@ int spdy_vdspec(spdy_plan *p, int nb, const double *ug, const double *vg, double
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!ug || !vg || !vorm || !divm)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
     RC(h2d(p, p->stage_a, ug, nb * grid_elems(p)));
     RC(h2d(p, p->stage_b, vg, nb * grid_elems(p)));
-    // The one-pass kernel writes vorticity/divergence while other workgroups still read grids: its outputs must
-    // not alias its inputs.  The multi-kernel path keeps its intermediate spectra in stage_c/d and lets vds write
-    // over the (by then consumed) grids in stage_a/b.
-    const bool one_pass = use_fused(p, nb);
-    double *o1 = one_pass ? p->stage_c : p->stage_a, *o2 = one_pass ? p->stage_d : p->stage_b;
-    RC(spdy_vdspec_dev(p, nb, p->stage_a, p->stage_b, o1, o2, kcos));
-    RC(d2h(p, vorm, o1, nb * spec_elems(p)));
-    RC(d2h(p, divm, o2, nb * spec_elems(p)));
+    // (the one-pass kernel writes vorticity/divergence while other workgroups still read grids: outputs never alias inputs)
+    RC(spdy_vdspec_dev(p, nb, p->stage_a, p->stage_b, p->stage_c, p->stage_d, kcos));
+    RC(d2h(p, vorm, p->stage_c, nb * spec_elems(p)));
+    RC(d2h(p, divm, p->stage_d, nb * spec_elems(p)));
     return sync(p);
-}
-
-/* ---------------------------------------------------------------- spectral-space tail */
-int spdy_hdiff_dev(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *d_dmp,
-                   const double *d_dmp1, double *fdt_out)
-{
-    NEED_DEVICE(p);
-    if (nlev < 0) return fail(SPDY_ERR_ARG, "nlev < 0");
-    KERNEL(spdy::launch_hdiff(p->dev, nlev, field, fdt_in, d_dmp, d_dmp1, fdt_out, p->stream));
-    return SPDY_OK;
-}
-
-int spdy_hdiff_multi_dev(spdy_plan *p, int nops, const spdy_hdiff_op *ops)
-{
-    NEED_DEVICE(p);
-    if (nops < 0 || nops > SPDY_HDIFF_MAX_OPS || (nops && !ops)) return fail(SPDY_ERR_ARG, "nops=%d outside [0, %d]", nops, (int)SPDY_HDIFF_MAX_OPS);
-    spdy::HdiffOps h{};
-    h.nops = nops;
-    for (int i = 0; i < nops; ++i) {
-        if (ops[i].nlev < 0 || (ops[i].nlev && (!ops[i].field || !ops[i].fdt_in || !ops[i].d_dmp || !ops[i].d_dmp1 || !ops[i].fdt_out)))
-            return fail(SPDY_ERR_ARG, "hdiff op %d: bad argument", i);
-        h.nlev[i] = ops[i].nlev; h.field[i] = ops[i].field; h.fdt[i] = ops[i].fdt_in;
-        h.dmp[i] = ops[i].d_dmp; h.dmp1[i] = ops[i].d_dmp1; h.out[i] = ops[i].fdt_out;
-    }
-    KERNEL(spdy::launch_hdiff_multi(p->dev, h, p->stream));
-    return SPDY_OK;
-}
-
-int spdy_hdiff(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *dmp,
-               const double *dmp1, double *fdt_out)
-{
-    NEED_DEVICE(p);
-    RC(check_batch(p, nlev));
-    if (nlev && (!field || !fdt_in || !dmp || !dmp1 || !fdt_out)) return fail(SPDY_ERR_ARG, "null pointer");
-    const size_t n = nlev * spec_elems(p), tn = (size_t)p->tab.mx * p->tab.nx;
-    RC(h2d(p, p->stage_a, field, n));
-    RC(h2d(p, p->stage_b, fdt_in, n));
-    RC(h2d(p, p->stage_c, dmp, tn));
-    RC(h2d(p, p->stage_d, dmp1, tn));
-    RC(spdy_hdiff_dev(p, nlev, p->stage_a, p->stage_b, p->stage_c, p->stage_d, p->stage_a));
-    RC(d2h(p, fdt_out, p->stage_a, n));
-    return sync(p);
-}
-
-int spdy_implicit_init(spdy_plan *p, double dt)
-{
-    NEED_PLAN(p);
-    const std::string err = p->tab.build_implicit(dt);
-    if (!err.empty()) return fail(SPDY_ERR_UNSUPPORTED, "implicit_init: %s", err.c_str());
-    if (p->device < 0) return SPDY_OK;
-    HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    const HostTables &t = p->tab;
-    const size_t tn = sizeof(double) * t.mx * t.nx;
-    const std::vector<double> *d1[3] = {&t.dmp1, &t.dmp1d, &t.dmp1s};
-    for (int i = 0; i < 3; ++i) HIP_TRY(hipMemcpy(p->d_dmp[3 + i], d1[i]->data(), tn, hipMemcpyHostToDevice));
-    struct { double *dst; const std::vector<double> *src; } up[6] = {
-        {p->d_xd, &t.xd}, {p->d_xc, &t.xc}, {p->d_xj, &t.xj}, {p->d_tref1, &t.tref1}, {p->d_dhsx, &t.dhsx}, {p->d_elz, &t.elz}};
-    for (auto &u : up) HIP_TRY(hipMemcpy(u.dst, u.src->data(), u.src->size() * sizeof(double), hipMemcpyHostToDevice));
-    return SPDY_OK;
-}
-
-int spdy_implicit_terms_dev(spdy_plan *p, double *divdt, double *tdt, double *psdt)
-{
-    NEED_DEVICE(p);
-    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "implicit_terms before implicit_init");
-    if (!divdt || !tdt || !psdt) return fail(SPDY_ERR_ARG, "null pointer");
-    KERNEL(spdy::launch_implicit(p->dev, divdt, tdt, psdt, p->stream));
-    return SPDY_OK;
-}
-
-int spdy_implicit_terms(spdy_plan *p, double *divdt, double *tdt, double *psdt)
-{
-    NEED_DEVICE(p);
-    if (p->max_batch < p->tab.kx) return fail(SPDY_ERR_ARG, "max_batch must be >= kx for the host implicit_terms");
-    if (!divdt || !tdt || !psdt) return fail(SPDY_ERR_ARG, "null pointer");
-    const size_t n = p->tab.kx * spec_elems(p);
-    RC(h2d(p, p->stage_a, divdt, n));
-    RC(h2d(p, p->stage_b, tdt, n));
-    RC(h2d(p, p->stage_c, psdt, spec_elems(p)));
-    RC(spdy_implicit_terms_dev(p, p->stage_a, p->stage_b, p->stage_c));
-    RC(d2h(p, divdt, p->stage_a, n));
-    RC(d2h(p, tdt, p->stage_b, n));
-    RC(d2h(p, psdt, p->stage_c, spec_elems(p)));
-    return sync(p);
-}
-
-int spdy_device_table(spdy_plan *p, const char *name, const double **d_ptr)
-{
-    NEED_DEVICE(p);
-    if (!name || !d_ptr) return fail(SPDY_ERR_ARG, "null argument");
-    static const char *names[6] = {"dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s"};
-    for (int i = 0; i < 6; ++i)
-        if (!std::strcmp(name, names[i])) {
-            if (i >= 3 && !p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "%s needs implicit_init first", name);
-            *d_ptr = p->d_dmp[i];
-            return SPDY_OK;
-        }
-    return fail(SPDY_ERR_ARG, "no device table '%s'", name);
 }
 
 /* ---------------------------------------------------------------- HIP graphs */
@@ -923,13 +875,16 @@ int spdy_graph_end(spdy_plan *p, spdy_graph **graph)
         delete g;
         return fail(SPDY_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
     }
+    p->graphs.push_back(g);
     *graph = g;
     return SPDY_OK;
 }
 
 int spdy_graph_launch(spdy_graph *g)
 {
-    if (!g || !g->exec) return fail(SPDY_ERR_ARG, "graph == NULL");
+    if (!g) return fail(SPDY_ERR_ARG, "graph == NULL");
+    if (!g->plan || !g->exec) return fail(SPDY_ERR_STATE, "the plan this graph was captured from has been destroyed");
+    HIP_TRY(hipSetDevice(g->plan->device));
     if (g->plan->capturing) return fail(SPDY_ERR_STATE, "cannot launch a graph while a capture is open");
     HIP_TRY(hipGraphLaunch(g->exec, g->plan->stream));
     return SPDY_OK;
@@ -938,6 +893,10 @@ int spdy_graph_launch(spdy_graph *g)
 int spdy_graph_destroy(spdy_graph *g)
 {
     if (!g) return SPDY_OK;
+    if (g->plan) {
+        auto &v = g->plan->graphs;
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == g) { v.erase(v.begin() + i); break; }
+    }
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;

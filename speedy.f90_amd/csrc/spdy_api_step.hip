@@ -1,0 +1,364 @@
+// C ABI (include/spdy.h), second half: the spectral-space tail of a time step (horizontal diffusion, semi-implicit
+// solve, spectral tendencies, geopotential, leapfrog/RAW filter), the level all-gather over RCCL and the output path.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "spdy_plan.hpp"
+
+using spdy::HostTables;
+using namespace spdy_detail;
+
+extern "C" {
+
+/* ---------------------------------------------------------------- sigma levels */
+int spdy_plan_set_sigma(spdy_plan *p, const double *hsg)
+{
+    NEED_PLAN(p);
+    NOT_CAPTURING(p, "spdy_plan_set_sigma");
+    const std::string err = p->tab.set_sigma(hsg);
+    if (!err.empty()) return fail(SPDY_ERR_ARG, "set_sigma: %s", err.c_str());
+    if (p->device < 0) return SPDY_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return upload_level_tables(p);
+}
+
+/* ---------------------------------------------------------------- horizontal diffusion */
+int spdy_hdiff_dev(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *d_dmp,
+                   const double *d_dmp1, double *fdt_out)
+{
+    NEED_DEVICE(p);
+    if (nlev < 0) return fail(SPDY_ERR_ARG, "nlev < 0");
+    if (nlev && (!field || !fdt_in || !d_dmp || !d_dmp1 || !fdt_out)) return fail(SPDY_ERR_ARG, "null device pointer");
+    KERNEL(spdy::launch_hdiff(p->dev, nlev, field, fdt_in, d_dmp, d_dmp1, fdt_out, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_hdiff_multi_dev(spdy_plan *p, int nops, const spdy_hdiff_op *ops)
+{
+    NEED_DEVICE(p);
+    if (nops < 0 || nops > SPDY_HDIFF_MAX_OPS || (nops && !ops)) return fail(SPDY_ERR_ARG, "nops=%d outside [0, %d]", nops, (int)SPDY_HDIFF_MAX_OPS);
+    spdy::HdiffOps h{};
+    h.nops = nops;
+    for (int i = 0; i < nops; ++i) {
+        if (ops[i].nlev < 0 || (ops[i].nlev && (!ops[i].field || !ops[i].fdt_in || !ops[i].d_dmp || !ops[i].d_dmp1 || !ops[i].fdt_out)))
+            return fail(SPDY_ERR_ARG, "hdiff op %d: bad argument", i);
+        h.nlev[i] = ops[i].nlev; h.field[i] = ops[i].field; h.fdt[i] = ops[i].fdt_in;
+        h.dmp[i] = ops[i].d_dmp; h.dmp1[i] = ops[i].d_dmp1; h.out[i] = ops[i].fdt_out;
+    }
+    KERNEL(spdy::launch_hdiff_multi(p->dev, h, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_hdiff(spdy_plan *p, int nlev, const double *field, const double *fdt_in, const double *dmp,
+               const double *dmp1, double *fdt_out)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, nlev));
+    if (nlev && (!field || !fdt_in || !dmp || !dmp1 || !fdt_out)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
+    const size_t n = nlev * spec_elems(p), tn = (size_t)p->tab.mx * p->tab.nx;
+    RC(h2d(p, p->stage_a, field, n));
+    RC(h2d(p, p->stage_b, fdt_in, n));
+    RC(h2d(p, p->stage_c, dmp, tn));            // both damping tables share stage_c (2*mx*nx <= ix*il) ...
+    RC(h2d(p, p->stage_c + tn, dmp1, tn));
+    RC(spdy_hdiff_dev(p, nlev, p->stage_a, p->stage_b, p->stage_c, p->stage_c + tn, p->stage_d));   // ... so the result has its own buffer
+    RC(d2h(p, fdt_out, p->stage_d, n));
+    return sync(p);
+}
+
+int spdy_device_table(spdy_plan *p, const char *name, const double **d_ptr)
+{
+    NEED_DEVICE(p);
+    if (!name || !d_ptr) return fail(SPDY_ERR_ARG, "null argument");
+    static const char *names[6] = {"dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s"};
+    for (int i = 0; i < 6; ++i)
+        if (!std::strcmp(name, names[i])) {
+            if (i >= 3 && !p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "%s needs implicit_init first", name);
+            *d_ptr = p->d_dmp[i];
+            return SPDY_OK;
+        }
+    return fail(SPDY_ERR_ARG, "no device table '%s'", name);
+}
+
+/* ---------------------------------------------------------------- semi-implicit solve */
+int spdy_implicit_init(spdy_plan *p, double dt)
+{
+    NEED_PLAN(p);
+    NOT_CAPTURING(p, "spdy_implicit_init (host table build + blocking upload)");
+    const std::string err = p->tab.build_implicit(dt);
+    if (!err.empty()) return fail(SPDY_ERR_UNSUPPORTED, "implicit_init: %s", err.c_str());
+    if (p->device < 0) return SPDY_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const HostTables &t = p->tab;
+    const size_t tn = sizeof(double) * t.mx * t.nx;
+    const std::vector<double> *d1[3] = {&t.dmp1, &t.dmp1d, &t.dmp1s};
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipMemcpy(p->d_dmp[3 + i], d1[i]->data(), tn, hipMemcpyHostToDevice));
+    struct { double *dst; const std::vector<double> *src; } up[6] = {
+        {p->d_xd, &t.xd}, {p->d_xc, &t.xc}, {p->d_xj, &t.xj}, {p->d_tref1, &t.tref1}, {p->d_dhsx, &t.dhsx}, {p->d_elz, &t.elz}};
+    for (auto &u : up) HIP_TRY(hipMemcpy(u.dst, u.src->data(), u.src->size() * sizeof(double), hipMemcpyHostToDevice));
+    return upload_level_tables(p);
+}
+
+int spdy_implicit_terms_dev(spdy_plan *p, double *divdt, double *tdt, double *psdt)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "implicit_terms before implicit_init");
+    if (!divdt || !tdt || !psdt) return fail(SPDY_ERR_ARG, "null pointer");
+    KERNEL(spdy::launch_implicit(p->dev, divdt, tdt, psdt, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_implicit_terms(spdy_plan *p, double *divdt, double *tdt, double *psdt)
+{
+    NEED_DEVICE(p);
+    if (p->max_batch < p->tab.kx) return fail(SPDY_ERR_ARG, "max_batch must be >= kx for the host implicit_terms");
+    if (!divdt || !tdt || !psdt) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
+    const size_t n = p->tab.kx * spec_elems(p);
+    RC(h2d(p, p->stage_a, divdt, n));
+    RC(h2d(p, p->stage_b, tdt, n));
+    RC(h2d(p, p->stage_c, psdt, spec_elems(p)));
+    RC(spdy_implicit_terms_dev(p, p->stage_a, p->stage_b, p->stage_c));
+    RC(d2h(p, divdt, p->stage_a, n));
+    RC(d2h(p, tdt, p->stage_b, n));
+    RC(d2h(p, psdt, p->stage_c, spec_elems(p)));
+    return sync(p);
+}
+
+/* ---------------------------------------------------------------- spectral side of a time step */
+int spdy_geopotential_dev(spdy_plan *p, const double *t, const double *phis, double *phi)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.sigma_ready) return fail(SPDY_ERR_STATE, "geopotential needs sigma levels (kx in {5,7,8} or spdy_plan_set_sigma)");
+    if (!t || !phis || !phi) return fail(SPDY_ERR_ARG, "null device pointer");
+    KERNEL(spdy::launch_geopotential(p->dev, t, phis, phi, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_geopotential(spdy_plan *p, const double *t, const double *phis, double *phi)
+{
+    NEED_DEVICE(p);
+    if (p->max_batch < p->tab.kx) return fail(SPDY_ERR_ARG, "max_batch must be >= kx for the host get_geopotential");
+    if (!t || !phis || !phi) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
+    const size_t n = p->tab.kx * spec_elems(p);
+    RC(h2d(p, p->stage_a, t, n));
+    RC(h2d(p, p->stage_b, phis, spec_elems(p)));
+    RC(spdy_geopotential_dev(p, p->stage_a, p->stage_b, p->stage_c));
+    RC(d2h(p, phi, p->stage_c, n));
+    return sync(p);
+}
+
+int spdy_spectral_tendencies_dev(spdy_plan *p, const double *div, const double *t, const double *ps, const double *phis,
+                                 double *divdt, double *tdt, double *psdt, double *phi)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "spectral_tendencies needs the reference temperature profile: call spdy_implicit_init first");
+    if (!div || !t || !ps || !phis || !divdt || !tdt || !psdt || !phi) return fail(SPDY_ERR_ARG, "null device pointer");
+    KERNEL(spdy::launch_spectral_tendencies(p->dev, div, t, ps, phis, divdt, tdt, psdt, phi, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_hdiff_step_dev(spdy_plan *p, const double *vor, const double *div, const double *t, const double *tr,
+                        const double *d_tcorh, const double *d_qcorh, double sdrag,
+                        double *vordt, double *divdt, double *tdt, double *trdt)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "hdiff_step needs dmp1*: call spdy_implicit_init first");
+    if (!p->tab.sigma_ready) return fail(SPDY_ERR_STATE, "hdiff_step needs sigma levels");
+    if (!vor || !div || !t || !d_tcorh || !vordt || !divdt || !tdt) return fail(SPDY_ERR_ARG, "null device pointer");
+    if ((tr != nullptr) != (trdt != nullptr) || (tr && !d_qcorh)) return fail(SPDY_ERR_ARG, "tracer arguments: tr, trdt and qcorh go together");
+    spdy::HdiffStep h{vor, div, t, tr, vordt, divdt, tdt, trdt, d_tcorh, d_qcorh,
+                      p->d_dmp[0], p->d_dmp[1], p->d_dmp[2], p->d_dmp[3], p->d_dmp[4], p->d_dmp[5], sdrag};
+    KERNEL(spdy::launch_hdiff_step(p->dev, h, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_step_fields_dev(spdy_plan *p, int nops, const spdy_step_op *ops, int j1, double dt, double eps, double wil)
+{
+    NEED_DEVICE(p);
+    if (nops < 0 || nops > SPDY_STEP_MAX_OPS || (nops && !ops)) return fail(SPDY_ERR_ARG, "nops=%d outside [0, %d]", nops, (int)SPDY_STEP_MAX_OPS);
+    if (j1 != 1 && j1 != 2) return fail(SPDY_ERR_ARG, "j1 must be 1 or 2");
+    spdy::StepOps s{};
+    s.nops = nops;
+    for (int i = 0; i < nops; ++i) {
+        if (ops[i].nlev < 0 || (ops[i].nlev && (!ops[i].field || !ops[i].fdt))) return fail(SPDY_ERR_ARG, "step op %d: bad argument", i);
+        s.nlev[i] = ops[i].nlev; s.field[i] = ops[i].field; s.fdt[i] = ops[i].fdt;
+    }
+    // time_stepping.f90:155-157: the tendency is truncated first whenever ix == 4*iy (true for T30 and T63)
+    const int do_trunct = p->tab.ix == 4 * p->tab.iy;
+    KERNEL(spdy::launch_step_fields(p->dev, s, j1, dt, eps, wil, do_trunct, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_step_field(spdy_plan *p, int nlev, int j1, double dt, double eps, double wil, double *field, double *fdt)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, 2 * nlev));
+    if (nlev && (!field || !fdt)) return fail(SPDY_ERR_ARG, "null pointer");
+    RC(ensure_staging(p));
+    const size_t n = nlev * spec_elems(p);
+    RC(h2d(p, p->stage_a, field, 2 * n));
+    RC(h2d(p, p->stage_b, fdt, n));
+    const spdy_step_op op{nlev, p->stage_a, p->stage_b};
+    RC(spdy_step_fields_dev(p, 1, &op, j1, dt, eps, wil));
+    RC(d2h(p, field, p->stage_a, 2 * n));
+    RC(d2h(p, fdt, p->stage_b, n));
+    return sync(p);
+}
+
+
+/* ---------------------------------------------------------------- level all-gather over RCCL (xGMI) */
+}  // extern "C"
+
+// RCCL is loaded on first use (dlopen by soname): single-GPU hosts never load it, and inside a process that already
+// carries a librccl.so.1 (e.g. PyTorch's) the same instance is shared instead of a second copy being mapped.
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    if (r.handle || !r.error.empty()) return r;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+        if ((r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!r.handle) { r.error = std::string("cannot load librccl: ") + dlerror(); return r; }
+#define SYM(field, name)                                                                       \
+    if (!(r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name)))) { r.error = std::string("librccl lacks ") + name; r.handle = nullptr; return r; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return r;
+}
+}  // namespace
+
+struct spdy_comm {
+    spdy_plan *plan = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+#define NCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) return fail(SPDY_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+
+extern "C" {
+
+int spdy_comm_unique_id(char *id)
+{
+    static_assert(sizeof(ncclUniqueId) == SPDY_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!id) return fail(SPDY_ERR_ARG, "null id");
+    if (!rccl().handle) return fail(SPDY_ERR_COMM, "%s", rccl().error.c_str());
+    ncclUniqueId u;
+    NCCL_TRY(rccl().GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof(u));
+    return SPDY_OK;
+}
+
+int spdy_comm_create(spdy_plan *p, int nranks, int rank, const char *id, spdy_comm **comm)
+{
+    NEED_DEVICE(p);
+    if (!comm) return fail(SPDY_ERR_ARG, "null comm pointer");
+    *comm = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(SPDY_ERR_ARG, "bad rank %d of %d / null id", rank, nranks);
+    NOT_CAPTURING(p, "spdy_comm_create");
+    if (!rccl().handle) return fail(SPDY_ERR_COMM, "%s", rccl().error.c_str());
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    spdy_comm *c = new spdy_comm;
+    c->plan = p; c->nranks = nranks; c->rank = rank;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(SPDY_ERR_COMM, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
+    }
+    *comm = c;
+    return SPDY_OK;
+}
+
+int spdy_comm_destroy(spdy_comm *c)
+{
+    if (!c) return SPDY_OK;
+    if (c->comm && rccl().handle) {
+        (void)hipSetDevice(c->plan->device);
+        (void)hipStreamSynchronize(c->plan->stream);
+        (void)rccl().CommDestroy(c->comm);
+    }
+    delete c;
+    return SPDY_OK;
+}
+
+int spdy_comm_level_range(const spdy_comm *c, int nlev, int *lo, int *hi)
+{
+    if (!c || !lo || !hi || nlev < 0) return fail(SPDY_ERR_ARG, "bad argument");
+    *lo = (int)(((long)nlev * c->rank) / c->nranks);
+    *hi = (int)(((long)nlev * (c->rank + 1)) / c->nranks);
+    return SPDY_OK;
+}
+
+/* In place: every array d_full[i] is a full (mx,nx,nlev) stack of which this rank has filled its own level block
+ * [lo, hi) (spdy_comm_level_range); afterwards every rank holds all levels.  One grouped RCCL operation for all
+ * narr arrays, enqueued on the plan's stream (graph-capturable).  Equal blocks -> one-shot ncclAllGather per array
+ * (each rank's block travels over its own xGMI link); ragged blocks -> one ncclBroadcast per rank and array.       */
+int spdy_allgather_levels_dev(spdy_comm *c, int nlev, int narr, double *const *d_full)
+{
+    if (!c) return fail(SPDY_ERR_ARG, "null comm");
+    spdy_plan *p = c->plan;
+    NEED_DEVICE(p);
+    if (narr < 0 || narr > 8 || (narr && !d_full) || nlev < 0) return fail(SPDY_ERR_ARG, "bad argument");
+    if (c->nranks == 1 || narr == 0 || nlev == 0) return SPDY_OK;
+    const size_t slab = spec_elems(p);                    // doubles per level
+    const bool even = nlev % c->nranks == 0;
+    NCCL_TRY(rccl().GroupStart());
+    for (int a = 0; a < narr; ++a) {
+        if (!d_full[a]) { (void)rccl().GroupEnd(); return fail(SPDY_ERR_ARG, "null array %d", a); }
+        if (even) {
+            const size_t cnt = (size_t)(nlev / c->nranks) * slab;
+            NCCL_TRY(rccl().AllGather(d_full[a] + (size_t)c->rank * cnt, d_full[a], cnt, ncclDouble, c->comm, p->stream));
+        } else {
+            for (int r = 0; r < c->nranks; ++r) {
+                const long lo = ((long)nlev * r) / c->nranks, hi = ((long)nlev * (r + 1)) / c->nranks;
+                if (hi > lo)
+                    NCCL_TRY(rccl().Broadcast(d_full[a] + lo * slab, d_full[a] + lo * slab, (size_t)(hi - lo) * slab, ncclDouble, r,
+                                              c->comm, p->stream));
+            }
+        }
+    }
+    NCCL_TRY(rccl().GroupEnd());
+    return SPDY_OK;
+}
+
+/* implicit_terms with the levels sharded over the ranks of `c` (implicit.f90:168-217 couples all levels of a
+ * coefficient): gather the level blocks of divdt and tdt (psdt is level-free and identical on every rank), then the
+ * solve on the full columns -- redundant on every rank, it is a few microseconds.                                */
+int spdy_implicit_terms_sharded_dev(spdy_comm *c, double *divdt, double *tdt, double *psdt)
+{
+    if (!c) return fail(SPDY_ERR_ARG, "null comm");
+    double *arr[2] = {divdt, tdt};
+    RC(spdy_allgather_levels_dev(c, c->plan->tab.kx, 2, arr));
+    return spdy_implicit_terms_dev(c->plan, divdt, tdt, psdt);
+}
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+// Complex helpers shared by the elementwise spectral-space kernels.  Operation order follows the reference's
+// Fortran expressions: real*complex scales both parts; "* (0.0, 1.0)" is the full complex multiply.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace spdy {
+
+#ifndef UNROLL
+#define UNROLL _Pragma("unroll")
+#endif
+
+struct cpx { double re, im; };
+__device__ __forceinline__ cpx ld(const double *a, long i) { const double2 v = *reinterpret_cast<const double2 *>(a + 2 * i); return {v.x, v.y}; }
+__device__ __forceinline__ void st(double *a, long i, cpx z) { *reinterpret_cast<double2 *>(a + 2 * i) = make_double2(z.re, z.im); }
+__device__ __forceinline__ cpx operator*(double r, cpx z) { return {r * z.re, r * z.im}; }
+__device__ __forceinline__ cpx operator+(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cpx operator-(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cpx operator-(cpx a) { return {-a.re, -a.im}; }
+__device__ __forceinline__ cpx times_i(cpx a) { return {a.re * 0.0 - a.im, a.re + a.im * 0.0}; }   // * (0,1)
+
+}  // namespace spdy

@@ -13,10 +13,10 @@
 // reference (tables come from spdy_tables.cpp); only FMA contraction and the order of the
 // Legendre sums differ -> agreement ~1e-15 relative, bar 1e-12.
 #include "spdy_kernels.hpp"
+#include "spdy_cpx.hpp"
 
 namespace spdy {
 
-#define UNROLL _Pragma("unroll")
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
@@ -712,15 +712,6 @@ __global__ __launch_bounds__(LEG_NT) void legendre_dir_kernel(DevPlan p, int nb,
 // ------------------------------------------------------------------------------------------
 // Spectral-space operators: one lane per complex coefficient (b, n, m).
 // ------------------------------------------------------------------------------------------
-struct cpx { double re, im; };
-__device__ __forceinline__ cpx ld(const double *a, long i) { const double2 v = *reinterpret_cast<const double2 *>(a + 2 * i); return {v.x, v.y}; }
-__device__ __forceinline__ void st(double *a, long i, cpx z) { *reinterpret_cast<double2 *>(a + 2 * i) = make_double2(z.re, z.im); }
-__device__ __forceinline__ cpx operator*(double r, cpx z) { return {r * z.re, r * z.im}; }
-__device__ __forceinline__ cpx operator+(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cpx operator-(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cpx operator-(cpx a) { return {-a.re, -a.im}; }
-__device__ __forceinline__ cpx times_i(cpx a) { return {a.re * 0.0 - a.im, a.re + a.im * 0.0}; }   // * (0,1)
-
 // laplacian / inverse_laplacian / trunct (spectral.f90:84-96, 229-233)
 __global__ void scale_op_kernel(DevPlan p, int op, long total, const double *__restrict__ in, double *__restrict__ out)
 {
@@ -805,79 +796,42 @@ __global__ void hdiff_kernel(int sz, long total, const double *__restrict__ fiel
     st(out, i, dmp1[e] * (ld(fdt, i) - dmp[e] * ld(field, i)));
 }
 
-// implicit_terms (implicit.f90:168-217): one lane per (m,n); the kx x kx mat-vecs run in
-// registers in the reference's summation order.
-constexpr int MAXK = 8;
-__global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *__restrict__ tdt, double *__restrict__ psdt)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x, sz = p.mx * p.nx, kx = p.kx;
-    if (e >= sz) return;
-    const int m = e % p.mx, n = e / p.mx, l = m + n;
-    cpx t[MAXK], ye[MAXK], yf[MAXK], d[MAXK];
-    cpx ps = ld(psdt, e);
-    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) { t[k] = ld(tdt, (long)k * sz + e); ye[k] = {0.0, 0.0}; }
-    UNROLL for (int k1 = 0; k1 < MAXK; ++k1) {
-        if (k1 < kx) {
-            UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) ye[k] = ye[k] + p.xd[k + kx * k1] * t[k1];
-        }
-    }
-    const double ez = p.elz[e];
-    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) {
-        ye[k] = ye[k] + p.tref1[k] * ps;
-        yf[k] = ld(divdt, (long)k * sz + e) + ez * ye[k];
-        d[k] = {0.0, 0.0};
-    }
-    if (l != 0) {
-        const double *xj = p.xj + (long)kx * kx * (l - 1);
-        UNROLL for (int k1 = 0; k1 < MAXK; ++k1) {
-            if (k1 < kx) {
-                UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) d[k] = d[k] + xj[k + kx * k1] * yf[k1];
-            }
-        }
-    }
-    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) ps = ps - p.dhsx[k] * d[k];
-    UNROLL for (int k = 0; k < MAXK; ++k) {
-        if (k < kx) {
-            UNROLL for (int k1 = 0; k1 < MAXK; ++k1) if (k1 < kx) t[k] = t[k] + p.xc[k + kx * k1] * d[k1];
-        }
-    }
-    UNROLL for (int k = 0; k < MAXK; ++k) if (k < kx) { st(divdt, (long)k * sz + e, d[k]); st(tdt, (long)k * sz + e, t[k]); }
-    st(psdt, e, ps);
-}
-
 #include "spdy_fused_t30.inc"
 
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
 // grid limit of the persistent kernels: 3 blocks per CU (the FFT kernels' LDS footprint allows exactly that)
-static int fft_grid_limit()
+static int fft_grid_limit(const DevPlan &p) { return 3 * (p.num_cu > 0 ? p.num_cu : 256); }
+
+static size_t legendre_inv_lds(const DevPlan &p) { return sizeof(double) * std::max(LEG_MG * (2 * 4 * p.ks_inv * 16 + 2), 32 * LEG_BT * 18); }
+static size_t legendre_dir_lds(const DevPlan &p) { return sizeof(double) * std::max(LEG_MG * (p.il * 16 + 2), p.nx * LEG_BT * 18); }
+
+// Function attributes are per device: the plan calls this once after hipSetDevice (spdy_plan_create), so a second
+// plan on another GPU of the same process gets its own > 64 KB dynamic-LDS limits.
+hipError_t prepare_device_kernels()
 {
-    static int limit = 0;
-    if (!limit) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        limit = 3 * cus;
+    struct { const void *fn; int bytes; } big[] = {
+        {reinterpret_cast<const void *>(s2g_fused_t30_kernel<0>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<1>), t30::S2G_LDS},
+        {reinterpret_cast<const void *>(s2g_fused_t30_kernel<2>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<3>), t30::S2G_LDS},
+        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<0>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<1>), t30::G2S_LDS},
+        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<2>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<3>), t30::G2S_LDS},
+        {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
+    for (auto &b : big) {
+        hipError_t e = hipFuncSetAttribute(b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.bytes);
+        if (e != hipSuccess) return e;
     }
-    return limit;
+    return hipSuccess;
 }
 
 hipError_t launch_legendre_inv(const DevPlan &p, int nb, const double *spec, double *four, hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
     const dim3 grid((nb + LEG_BT - 1) / LEG_BT, (p.mx + LEG_MG - 1) / LEG_MG);
-    const size_t lds = sizeof(double) * std::max(LEG_MG * (2 * 4 * p.ks_inv * 16 + 2), 32 * LEG_BT * 18);   // B image / output lines
+    const size_t lds = legendre_inv_lds(p);   // B image / output lines
     if (p.jt == 2) hipLaunchKernelGGL(legendre_inv_kernel<2>, grid, dim3(LEG_NT), lds, s, p, nb, spec, four);
-    else if (p.jt == 3) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(legendre_inv_kernel<3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(legendre_inv_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, spec, four);
-    } else return hipErrorInvalidValue;
+    else if (p.jt == 3) hipLaunchKernelGGL(legendre_inv_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, spec, four);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -886,19 +840,11 @@ hipError_t launch_legendre_dir(const DevPlan &p, int nb, const double *four, dou
     if (nb <= 0) return hipSuccess;
     if (p.il != (p.nt_dir == 3 ? 96 : 48)) return hipErrorInvalidValue;
     const int ntiles = ((nb + LEG_BT - 1) / LEG_BT) * ((p.mx + LEG_MG - 1) / LEG_MG);
-    const size_t lds = sizeof(double) * std::max(LEG_MG * (p.il * 16 + 2), p.nx * LEG_BT * 18);   // Fourier image / output lines
-    const dim3 grid(std::min(ntiles, (int)(160 * 1024 / lds) * fft_grid_limit() / 3));              // persistent: resident blocks only
+    const size_t lds = legendre_dir_lds(p);   // Fourier image / output lines
+    const dim3 grid(std::min(ntiles, (int)(160 * 1024 / lds) * fft_grid_limit(p) / 3));              // persistent: resident blocks only
     if (p.nt_dir == 1) hipLaunchKernelGGL(legendre_dir_kernel<1>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
-    else if (p.nt_dir == 3) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(legendre_dir_kernel<3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(legendre_dir_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
-    } else return hipErrorInvalidValue;
+    else if (p.nt_dir == 3) hipLaunchKernelGGL(legendre_dir_kernel<3>, grid, dim3(LEG_NT), lds, s, p, nb, four, spec);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -908,7 +854,7 @@ hipError_t launch_fourier_inv(const DevPlan &p, int nb, const double *four, cons
     if (nb <= 0) return hipSuccess;
     const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
     const int per_cu = 160 * 1024 / ((FFT_ROWS * (p.ix + 1) + 4 * 48 + FFT_ROWS) * 8);   // LDS-resident blocks per CU
-    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, per_cu * fft_grid_limit() / 3);
+    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, per_cu * fft_grid_limit(p) / 3);
     if (p.fs != (2 * p.mx + 15) / 16 * 16) return hipErrorInvalidValue;
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_inv_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, four, grid, p.cosgr,
@@ -926,7 +872,7 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
     if (nb <= 0) return hipSuccess;
     const int nrows = nb * p.il, FFT_ROWS = fft_rows(p.ix);
     const int per_cu = 160 * 1024 / ((FFT_ROWS * (p.ix + 1) + 4 * 48 + FFT_ROWS) * 8);   // LDS-resident blocks per CU
-    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, per_cu * fft_grid_limit() / 3);
+    const int nblk = std::min((nrows + FFT_ROWS - 1) / FFT_ROWS, per_cu * fft_grid_limit(p) / 3);
     if (p.fs != (2 * p.mx + 15) / 16 * 16) return hipErrorInvalidValue;
     if (p.ix == 96 && p.mx == 31)
         hipLaunchKernelGGL((fourier_dir_kernel<96, 62>), dim3(nblk), dim3(FFT_ROWS * 2), 0, s, grid, gscale, four,
@@ -996,14 +942,6 @@ hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const d
     const long total = (long)nlev * p.mx * p.nx;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(hdiff_kernel, blocks_for(total), dim3(256), 0, s, p.mx * p.nx, total, field, fdt, dmp, dmp1, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s)
-{
-    if (p.kx > MAXK) return hipErrorInvalidValue;
-    const int sz = p.mx * p.nx;
-    hipLaunchKernelGGL(implicit_kernel, dim3((sz + 63) / 64), dim3(64), 0, s, p, divdt, tdt, psdt);
     return hipGetLastError();
 }
 

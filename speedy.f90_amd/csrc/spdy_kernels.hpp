@@ -7,6 +7,7 @@ namespace spdy {
 // Device-side view of a plan: dimensions + table pointers (all device memory).
 struct DevPlan {
     int trunc, ix, iy, il, kx, nx, mx;
+    int num_cu;    // compute units of the plan's device (sizes the persistent launches; host-side use)
     int fs;        // row stride (doubles) of the Fourier workspace: 2*mx rounded up to 16
     int ks_inv;    // k-steps (of 4 n's) per parity in the inverse-Legendre A table
     int jt;        // 16-latitude tiles per hemisphere (ceil(iy/16))
@@ -26,7 +27,14 @@ struct DevPlan {
     const double *el2, *elm2, *trfilt, *gradx, *gradym, *gradyp, *uvdx, *uvdym, *uvdyp, *vddym, *vddyp;
     // implicit tables
     const double *xd, *xc, *xj, *tref1, *dhsx, *elz;
+    // per-level tables [kx]: sigma-level functions (geometry.f90:51-60, geopotential.f90:22-30,53,
+    // horizontal_diffusion.f90:70-82) and the reference temperature profile (implicit.f90:62-67);
+    // rgtref = rgas*tref.  tref* are filled by spdy_implicit_init, the others whenever sigma levels exist.
+    const double *dhs, *dhsr, *fsgr, *tref, *tref2, *tref3, *rgtref, *xgeop1, *xgeop2, *corf, *tcorv, *qcorv;
+    const double *coriol;   // [il] 2*omega*sin(lat) (geometry.f90:89), southernmost row first
+    double rgas, akap;      // physical_constants.f90:22-24 (float32 literals widened)
 };
+constexpr int LEVTAB_COUNT = 12;   // number of per-level tables above (one device allocation of LEVTAB_COUNT*kx doubles)
 
 // FFTPACK twiddles / constants for one resolution; copied to __constant__ memory once.
 struct FftConstants {
@@ -78,5 +86,31 @@ struct HdiffOps {   // up to 8 independent diffusion operations, passed by value
 };
 hipError_t launch_hdiff_multi(const DevPlan &p, const HdiffOps &ops, hipStream_t s);
 hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s);
+
+// ---- spectral side of a time step (spdy_step.hip) ----
+// step_field_2d/3d (time_stepping.f90:121-167): up to 8 prognostic arrays [2][nlev][nx][mx] + their tendencies in one launch
+struct StepOps {
+    int nops, nlev[8];
+    double *field[8], *fdt[8];
+};
+hipError_t launch_step_fields(const DevPlan &p, const StepOps &ops, int j1, double dt, double eps, double wil, int do_trunct,
+                              hipStream_t s);
+// the diffusion block of `step` (time_stepping.f90:62-96) incl. the orographic corrections and the stratospheric drag
+struct HdiffStep {
+    const double *vor, *div, *t, *tr;            // time level 1 of the prognostics, [kx][nx][mx] complex
+    double *vordt, *divdt, *tdt, *trdt;          // tendencies, in place
+    const double *tcorh, *qcorh;                 // [nx][mx] complex (horizontal_diffusion.f90:31-32)
+    const double *dmp, *dmpd, *dmps, *dmp1, *dmp1d, *dmp1s;
+    double sdrag;
+};
+hipError_t launch_hdiff_step(const DevPlan &p, const HdiffStep &h, hipStream_t s);
+// get_geopotential (geopotential.f90:33-57)
+hipError_t launch_geopotential(const DevPlan &p, const double *t, const double *phis, double *phi, hipStream_t s);
+// get_spectral_tendencies (tendencies.f90:242-293); phi is written as the reference's module variable is
+hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const double *t, const double *ps, const double *phis,
+                                      double *divdt, double *tdt, double *psdt, double *phi, hipStream_t s);
+// once per device, before the first launch: raises the dynamic-LDS limit of every kernel that needs > 64 KB
+hipError_t prepare_device_kernels();
+hipError_t prepare_device_step_kernels(int kx);
 
 }  // namespace spdy

@@ -1,0 +1,86 @@
+// Internal: the plan object behind include/spdy.h and the helpers shared by the C-ABI translation units
+// (spdy_api.hip: plan, transforms, operators, graphs; spdy_api_step.hip: time-step tail, collectives, output).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/spdy.h"
+#include "spdy_kernels.hpp"
+#include "spdy_tables.hpp"
+
+struct spdy_graph {
+    struct spdy_plan *plan = nullptr;   // nullptr once the plan is gone: the graph is then dead (SPDY_ERR_STATE)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct spdy_plan {
+    spdy::HostTables tab;
+    int max_batch = 0;
+    int device = -1;
+    spdy::DevPlan dev{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<void *> allocs;       // everything hipMalloc'ed for this plan
+    double *four = nullptr;           // [max_batch][il][fs] Fourier workspace (four-kernel path only; allocated on demand)
+    // host-pointer API staging: four buffers of max_batch grids each, allocated at the first host-pointer call
+    double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;
+    size_t stage_elems = 0;
+    double *tmp_c = nullptr, *tmp_d = nullptr;   // max_batch spectra each; allocated with `four` (multi-kernel operator sequences)
+    int *d_kcos = nullptr;
+    // device copies of dt-dependent tables
+    double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
+    double *d_levtab = nullptr;       // [LEVTAB_COUNT][kx] per-level tables (DevPlan::dhs ... qcorv)
+    int num_cu = 256;
+    int wg_per_cu = 1;                // fused kernels: one 448-thread wave-specialised workgroup per CU
+    int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
+    // optional per-kernel timing (HIP events on the launch stream)
+    bool profiling = false;
+    bool capturing = false;           // between spdy_graph_begin and spdy_graph_end
+    struct Span { int kind; hipEvent_t t0, t1; };
+    std::vector<Span> spans;
+    std::vector<spdy_graph *> graphs; // graphs captured from this plan that are still alive
+};
+
+namespace spdy_detail {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int dev_alloc(spdy_plan *p, size_t bytes, void **out);
+int check_batch(const spdy_plan *p, int nb);
+int h2d(spdy_plan *p, double *dst, const double *src, size_t n);
+int d2h(spdy_plan *p, double *dst, const double *src, size_t n);
+int sync(spdy_plan *p);
+int ensure_staging(spdy_plan *p);     // host-pointer entry points call this first
+int ensure_four(spdy_plan *p);        // four-kernel path workspace
+int upload_level_tables(spdy_plan *p);
+
+inline size_t spec_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.nx; }
+inline size_t grid_elems(const spdy_plan *p) { return (size_t)p->tab.ix * p->tab.il; }
+inline size_t four_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.il; }
+
+}  // namespace spdy_detail
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return spdy_detail::fail(SPDY_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_PLAN(p)                                                                   \
+    do {                                                                               \
+        if (!(p)) return spdy_detail::fail(SPDY_ERR_ARG, "null plan");                 \
+    } while (0)
+#define NEED_DEVICE(p)                                                                                       \
+    do {                                                                                                     \
+        NEED_PLAN(p);                                                                                        \
+        if ((p)->device < 0) return spdy_detail::fail(SPDY_ERR_NO_DEVICE, "host-only plan: no HIP device, no CPU fallback"); \
+        HIP_TRY(hipSetDevice((p)->device));                                                                  \
+    } while (0)
+#define NOT_CAPTURING(p, what)                                                                               \
+    do {                                                                                                     \
+        if ((p)->capturing) return spdy_detail::fail(SPDY_ERR_STATE, "%s is not possible while a graph capture is open", what); \
+    } while (0)
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define KERNEL(expr) HIP_TRY(expr)

@@ -1,0 +1,251 @@
+// gfx950 kernels for the spectral-space side of a speedy.f90 time step: everything between the direct transforms
+// of step n and the inverse transforms of step n+1, so that prognostic spectra can stay in HBM across steps.
+//   implicit_terms            implicit.f90:168-217       (any number of levels)
+//   get_spectral_tendencies   tendencies.f90:242-293
+//   get_geopotential          geopotential.f90:33-57
+//   diffusion block of step   time_stepping.f90:62-96    (7 x do_horizontal_diffusion + ctmp + sdrag)
+//   step_field_2d/3d          time_stepping.f90:121-167  (leapfrog + Robert-Asselin-Williams filter + trunct)
+// All of it is elementwise per spectral coefficient (m,n) with short sequential loops over the kx levels: HBM/L2-bound
+// work on a few hundred KB, one lane per coefficient (or per coefficient x level), reference operation order.
+#include "spdy_kernels.hpp"
+#include "spdy_cpx.hpp"
+
+#include <algorithm>
+
+namespace spdy {
+
+// ------------------------------------------------------------------------------------------
+// implicit_terms (implicit.f90:168-217).  Block = 64 coefficients x KY level rows (one wave per row, so the
+// kx x kx matrices xd, xc are wave-uniform scalar loads; xj depends on l = m'+n per lane).  The three
+// mat-vecs exchange their level vectors through LDS; every sum runs in the reference's order.
+// ------------------------------------------------------------------------------------------
+__global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *__restrict__ tdt, double *__restrict__ psdt)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];           // [3][kx][64] complex
+    const int kx = p.kx, sz = p.mx * p.nx, tx = threadIdx.x, ty = threadIdx.y, ky = blockDim.y;
+    const int e = blockIdx.x * 64 + tx;
+    const bool valid = e < sz;
+    const int ec = valid ? e : sz - 1;
+    const int m = ec % p.mx, n = ec / p.mx, l = m + n;
+    double *tl = sm, *yl = sm + (size_t)kx * 128, *dl = sm + (size_t)kx * 256;
+    auto at = [&](double *b, int k) { return b + ((size_t)k * 64 + tx) * 2; };
+    for (int k = ty; k < kx; k += ky) {
+        const cpx v = ld(tdt, (long)k * sz + ec);
+        at(tl, k)[0] = v.re; at(tl, k)[1] = v.im;
+    }
+    __syncthreads();
+    const cpx ps0 = ld(psdt, ec);
+    const double ez = p.elz[ec];
+    for (int k = ty; k < kx; k += ky) {                                   // ye = xd*tdt + tref1*psdt ; yf = divdt + elz*ye
+        cpx ye = {0.0, 0.0};
+        for (int k1 = 0; k1 < kx; ++k1) ye = ye + p.xd[k + kx * k1] * cpx{at(tl, k1)[0], at(tl, k1)[1]};
+        ye = ye + p.tref1[k] * ps0;
+        const cpx yf = ld(divdt, (long)k * sz + ec) + ez * ye;
+        at(yl, k)[0] = yf.re; at(yl, k)[1] = yf.im;
+    }
+    __syncthreads();
+    for (int k = ty; k < kx; k += ky) {                                   // divdt = xj(:,:,l)*yf   (l = 0: stays 0)
+        cpx d = {0.0, 0.0};
+        if (l != 0) {
+            const double *xj = p.xj + (long)kx * kx * (l - 1);
+            for (int k1 = 0; k1 < kx; ++k1) d = d + xj[k + kx * k1] * cpx{at(yl, k1)[0], at(yl, k1)[1]};
+        }
+        at(dl, k)[0] = d.re; at(dl, k)[1] = d.im;
+    }
+    __syncthreads();
+    if (ty == 0 && valid) {                                               // psdt = psdt - sum_k dhsx(k)*divdt(k)
+        cpx ps = ps0;
+        for (int k = 0; k < kx; ++k) ps = ps - p.dhsx[k] * cpx{at(dl, k)[0], at(dl, k)[1]};
+        st(psdt, e, ps);
+    }
+    for (int k = ty; k < kx; k += ky) {                                   // tdt = tdt + xc*divdt
+        cpx t = {at(tl, k)[0], at(tl, k)[1]};
+        for (int k1 = 0; k1 < kx; ++k1) t = t + p.xc[k + kx * k1] * cpx{at(dl, k1)[0], at(dl, k1)[1]};
+        if (valid) {
+            st(tdt, (long)k * sz + e, t);
+            st(divdt, (long)k * sz + e, cpx{at(dl, k)[0], at(dl, k)[1]});
+        }
+    }
+}
+
+static size_t implicit_lds(int kx) { return (size_t)3 * kx * 64 * 16; }
+
+hipError_t prepare_device_step_kernels(int kx)
+{
+    if (implicit_lds(kx) <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(implicit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)implicit_lds(kx));
+}
+
+hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s)
+{
+    const int sz = p.mx * p.nx, ky = std::min(p.kx, 16);
+    if (implicit_lds(p.kx) > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(implicit_kernel, dim3((sz + 63) / 64), dim3(64, ky), implicit_lds(p.kx), s, p, divdt, tdt, psdt);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// step_field_2d / step_field_3d (time_stepping.f90:121-167), several prognostic arrays per launch (blockIdx.y).
+//   field: (mx,nx,nlev,2) -- both time levels, level 1 first; fdt: (mx,nx,nlev), truncated in place like the
+//   reference's intent(inout) dummy.  The second filter statement reads the already updated level-1 value (and
+//   the updated output(:,:,j1) when j1 == 1), exactly as the Fortran array statements do.
+// ------------------------------------------------------------------------------------------
+__global__ void step_fields_kernel(DevPlan p, StepOps ops, int j1, double dt, double eps, double wil, int do_trunct)
+{
+    const int op = blockIdx.y, sz = p.mx * p.nx;
+    const long total = (long)ops.nlev[op] * sz, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    double *f = ops.field[op], *fdt = ops.fdt[op];
+    cpx fd = ld(fdt, i);
+    if (do_trunct) {                                                      // trunct (spectral.f90:229-233)
+        fd = p.trfilt[(int)(i % sz)] * fd;
+        st(fdt, i, fd);
+    }
+    const cpx o1 = ld(f, i), o2 = ld(f, total + i);
+    const cpx fnew = o1 + dt * fd;
+    const cpx oj = j1 == 1 ? o1 : o2;
+    const cpx n1 = oj + (wil * eps) * ((o1 - 2.0 * oj) + fnew);
+    const cpx oj2 = j1 == 1 ? n1 : o2;
+    const cpx n2 = fnew - ((1.0 - wil) * eps) * ((n1 - 2.0 * oj2) + fnew);
+    st(f, i, n1);
+    st(f, total + i, n2);
+}
+
+hipError_t launch_step_fields(const DevPlan &p, const StepOps &ops, int j1, double dt, double eps, double wil, int do_trunct,
+                              hipStream_t s)
+{
+    int maxlev = 0;
+    for (int i = 0; i < ops.nops; ++i) maxlev = std::max(maxlev, ops.nlev[i]);
+    const long total = (long)maxlev * p.mx * p.nx;
+    if (ops.nops <= 0 || total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(step_fields_kernel, dim3((unsigned)((total + 255) / 256), ops.nops), dim3(256), 0, s, p, ops, j1, dt, eps,
+                       wil, do_trunct);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// The diffusion block of `step` (time_stepping.f90:62-96): one lane per (level, coefficient), four prognostics.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ cpx hd(cpx field, cpx fdt, double dmp, double dmp1) { return dmp1 * (fdt - dmp * field); }
+
+__global__ void hdiff_step_kernel(DevPlan p, HdiffStep h)
+{
+    const int sz = p.mx * p.nx;
+    const long total = (long)p.kx * sz, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i % sz), k = (int)(i / sz), m = e % p.mx;
+    const double dmp = h.dmp[e], dmpd = h.dmpd[e], dmps = h.dmps[e], dmp1 = h.dmp1[e], dmp1d = h.dmp1d[e], dmp1s = h.dmp1s[e];
+    const cpx vo = ld(h.vor, i), dv = ld(h.div, i);
+    cpx vdt = hd(vo, ld(h.vordt, i), dmp, dmp1);                           // :63-64
+    cpx ddt = hd(dv, ld(h.divdt, i), dmpd, dmp1d);
+    const cpx ctmp = ld(h.t, i) + p.tcorv[k] * ld(h.tcorh, e);            // :66-72
+    cpx tdt = hd(ctmp, ld(h.tdt, i), dmp, dmp1);                          // :74
+    if (m == 0 && k == 0) {                                               // :77-81 zonal-mean wind drag, top level
+        vdt = vdt - h.sdrag * vo;
+        ddt = ddt - h.sdrag * dv;
+    }
+    vdt = hd(vo, vdt, dmps, dmp1s);                                       // :83-85
+    ddt = hd(dv, ddt, dmps, dmp1s);
+    tdt = hd(ctmp, tdt, dmps, dmp1s);
+    st(h.vordt, i, vdt);
+    st(h.divdt, i, ddt);
+    st(h.tdt, i, tdt);
+    if (h.tr) {                                                           // :88-96 (ntr = 1)
+        const cpx cq = ld(h.tr, i) + p.qcorv[k] * ld(h.qcorh, e);
+        st(h.trdt, i, hd(cq, ld(h.trdt, i), dmpd, dmp1d));
+    }
+}
+
+hipError_t launch_hdiff_step(const DevPlan &p, const HdiffStep &h, hipStream_t s)
+{
+    const long total = (long)p.kx * p.mx * p.nx;
+    hipLaunchKernelGGL(hdiff_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, h);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// get_geopotential (geopotential.f90:33-57): hydrostatic integration from the bottom level up, then the
+// lapse-rate correction of the zonal (m' = 0) coefficients.  The recursion runs on the uncorrected values,
+// as the reference's three separate loops do.  One lane per coefficient.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void geopotential_column(const DevPlan &p, int e, int sz, bool zonal, const double *t, cpx phis,
+                                                    double *phi)
+{
+    const int kx = p.kx;
+    cpx tk1 = ld(t, (long)(kx - 1) * sz + e);
+    cpx ph = phis + p.xgeop1[kx - 1] * tk1;
+    st(phi, (long)(kx - 1) * sz + e, ph);
+    for (int k = kx - 2; k >= 0; --k) {
+        const cpx tk = ld(t, (long)k * sz + e);
+        ph = (ph + p.xgeop2[k + 1] * tk1) + p.xgeop1[k] * tk;
+        cpx out = ph;
+        if (zonal && k >= 1) out = ph + p.corf[k] * (tk1 - ld(t, (long)(k - 1) * sz + e));
+        st(phi, (long)k * sz + e, out);
+        tk1 = tk;
+    }
+}
+
+__global__ void geopotential_kernel(DevPlan p, const double *__restrict__ t, const double *__restrict__ phis, double *__restrict__ phi)
+{
+    const int sz = p.mx * p.nx, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sz) return;
+    geopotential_column(p, e, sz, e % p.mx == 0, t, ld(phis, e), phi);
+}
+
+hipError_t launch_geopotential(const DevPlan &p, const double *t, const double *phis, double *phi, hipStream_t s)
+{
+    const int sz = p.mx * p.nx;
+    hipLaunchKernelGGL(geopotential_kernel, dim3((sz + 63) / 64), dim3(64), 0, s, p, t, phis, phi);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// get_spectral_tendencies (tendencies.f90:242-293).  One lane per coefficient; the level recurrences stream
+// through registers (two passes over div, one over t), no per-level arrays.
+// ------------------------------------------------------------------------------------------
+__global__ void spectral_tendencies_kernel(DevPlan p, const double *__restrict__ div, const double *__restrict__ t,
+                                           const double *__restrict__ ps, const double *__restrict__ phis,
+                                           double *__restrict__ divdt, double *__restrict__ tdt, double *__restrict__ psdt,
+                                           double *__restrict__ phi)
+{
+    const int sz = p.mx * p.nx, kx = p.kx, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sz) return;
+    // vertical mean divergence and pressure tendency (:256-263)
+    cpx dmean = {0.0, 0.0};
+    for (int k = 0; k < kx; ++k) dmean = dmean + p.dhs[k] * ld(div, (long)k * sz + e);
+    cpx pst = ld(psdt, e) - dmean;
+    if (e == 0) pst = {0.0, 0.0};
+    st(psdt, e, pst);
+    // sigma-dot and temperature tendency (:265-285)
+    cpx sig = {0.0, 0.0}, dumk = {0.0, 0.0};
+    for (int k = 0; k < kx; ++k) {
+        cpx sig1 = {0.0, 0.0}, dumk1 = {0.0, 0.0};
+        if (k < kx - 1) {
+            sig1 = sig - p.dhs[k] * (ld(div, (long)k * sz + e) - dmean);
+            dumk1 = (p.tref[k + 1] - p.tref[k]) * sig1;
+        }
+        const cpx td = ((ld(tdt, (long)k * sz + e) - p.dhsr[k] * (dumk1 + dumk)) + p.tref3[k] * (sig1 + sig)) - p.tref2[k] * dmean;
+        st(tdt, (long)k * sz + e, td);
+        sig = sig1;
+        dumk = dumk1;
+    }
+    // geopotential and divergence tendency (:287-292): divdt = divdt - laplacian(phi + rgas*tref*ps)
+    geopotential_column(p, e, sz, e % p.mx == 0, t, ld(phis, e), phi);
+    const cpx psv = ld(ps, e);
+    const double l2 = p.el2[e];
+    for (int k = 0; k < kx; ++k) {
+        const cpx x = ld(phi, (long)k * sz + e) + p.rgtref[k] * psv;
+        st(divdt, (long)k * sz + e, ld(divdt, (long)k * sz + e) - l2 * (-x));
+    }
+}
+
+hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const double *t, const double *ps, const double *phis,
+                                      double *divdt, double *tdt, double *psdt, double *phi, hipStream_t s)
+{
+    const int sz = p.mx * p.nx;
+    hipLaunchKernelGGL(spectral_tendencies_kernel, dim3((sz + 63) / 64), dim3(64), 0, s, p, div, t, ps, phis, divdt, tdt, psdt, phi);
+    return hipGetLastError();
+}
+
+}  // namespace spdy

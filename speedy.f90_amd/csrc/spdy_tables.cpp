@@ -17,7 +17,8 @@ const double kCp = static_cast<double>(1004.0f);
 const double kGammaLapse = static_cast<double>(6.0f);
 const double kThd = static_cast<double>(2.4f), kThdd = static_cast<double>(2.4f), kThds = static_cast<double>(12.0f);
 const double kAlph = static_cast<double>(0.5f);
-inline double akap() { return static_cast<double>(2.0f / 7.0f); }
+const double kOmega = static_cast<double>(7.292e-05f);
+inline double kap32() { return static_cast<double>(2.0f / 7.0f); }
 
 // sin(latitude) of the "Gaussian" rows is the only libm-cosf-dependent table
 // (geometry.f90:68).  The values the reference produces (flang / glibc) are pinned here as
@@ -37,6 +38,39 @@ const uint32_t kSiaT63[48] = {
 
 inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
+// Everything that is a function of the half levels hsg alone:
+//   geometry.f90:51-60 (dhs, fsg, dhsr, fsgr), geopotential.f90:22-30 + :52-53 (xgeop1, xgeop2, corf),
+//   horizontal_diffusion.f90:70-82 (tcorv, qcorv)
+void make_sigma_derived(HostTables &t)
+{
+    const int kx = t.kx;
+    for (int k = 0; k < kx; ++k) {
+        t.dhs[k] = t.hsg[k + 1] - t.hsg[k];
+        t.fsg[k] = 0.5 * (t.hsg[k + 1] + t.hsg[k]);
+    }
+    for (int k = 0; k < kx; ++k) {
+        t.dhsr[k] = 0.5 / t.dhs[k];
+        t.fsgr[k] = kap32() / (2.0 * t.fsg[k]);
+    }
+    const double rgas = kap32() * kCp;
+    for (int k = 0; k < kx; ++k) {
+        t.xgeop1[k] = rgas * std::log(t.hsg[k + 1] / t.fsg[k]);
+        if (k != kx - 1) t.xgeop2[k + 1] = rgas * std::log(t.fsg[k + 1] / t.hsg[k + 1]);
+    }
+    for (int k = 0; k < kx; ++k) t.corf[k] = 0.0;
+    for (int k = 1; k + 1 < kx; ++k)      // geopotential.f90:53 (left-to-right: ((xgeop1*0.5)*log)/log)
+        t.corf[k] = t.xgeop1[k] * 0.5 * std::log(t.hsg[k + 1] / t.fsg[k]) / std::log(t.fsg[k + 1] / t.fsg[k - 1]);
+    // horizontal_diffusion.f90:70-82: rgam = rgas*gamma/(1000.*grav), qexp = hscale/hshum (float32 literals widened)
+    const double rgam = rgas * kGammaLapse / (1000.0 * kGrav);
+    const double qexp = static_cast<double>(7.5f) / static_cast<double>(2.5f);
+    for (int k = 0; k < kx; ++k) t.tcorv[k] = t.qcorv[k] = 0.0;
+    for (int k = 1; k < kx; ++k) {
+        t.tcorv[k] = std::pow(t.fsg[k], rgam);
+        if (k > 1) t.qcorv[k] = std::pow(t.fsg[k], qexp);
+    }
+    t.sigma_ready = true;
+}
+
 // ---- geometry.f90:35-89 -----------------------------------------------------------------
 void make_geometry(HostTables &t)
 {
@@ -46,16 +80,12 @@ void make_geometry(HostTables &t)
     const float *lev = t.kx == 8 ? lev8 : t.kx == 7 ? lev7 : t.kx == 5 ? lev5 : nullptr;
     t.hsg.assign(t.kx + 1, 0.0);
     t.dhs.assign(t.kx, 0.0); t.fsg.assign(t.kx, 0.0); t.dhsr.assign(t.kx, 0.0); t.fsgr.assign(t.kx, 0.0);
+    t.xgeop1.assign(t.kx, 0.0); t.xgeop2.assign(t.kx, 0.0); t.corf.assign(t.kx, 0.0);
+    t.tcorv.assign(t.kx, 0.0); t.qcorv.assign(t.kx, 0.0);
+    t.sigma_ready = false;
     if (lev) {
         for (int k = 0; k <= t.kx; ++k) t.hsg[k] = static_cast<double>(lev[k]);
-        for (int k = 0; k < t.kx; ++k) {
-            t.dhs[k] = t.hsg[k + 1] - t.hsg[k];
-            t.fsg[k] = 0.5 * (t.hsg[k + 1] + t.hsg[k]);
-        }
-        for (int k = 0; k < t.kx; ++k) {
-            t.dhsr[k] = 0.5 / t.dhs[k];
-            t.fsgr[k] = akap() / (2.0 * t.fsg[k]);
-        }
+        make_sigma_derived(t);
     }
     t.sia_half.assign(t.iy, 0.0);
     t.coa_half.assign(t.il, 0.0);
@@ -75,6 +105,15 @@ void make_geometry(HostTables &t)
         t.cosgr[j - 1] = t.cosgr[jn] = 1.0 / c;
         t.cosgr2[j - 1] = t.cosgr2[jn] = 1.0 / (c * c);
     }
+    // coriol = 2.0*omega*sia with sia(j) = -sia_half(j), sia(il+1-j) = +sia_half(j)   (geometry.f90:70-71, 89)
+    t.coriol.assign(t.il, 0.0);
+    for (int j = 0; j < t.iy; ++j) {
+        t.coriol[j] = 2.0 * kOmega * (-t.sia_half[j]);
+        t.coriol[t.il - 1 - j] = 2.0 * kOmega * t.sia_half[j];
+    }
+    t.akap = kap32();
+    t.rgas = kap32() * kCp;
+    t.grav = kGrav;
 }
 
 // ---- fftpack.f90:1-67 rffti1 --------------------------------------------------------------
@@ -323,11 +362,26 @@ std::string HostTables::build(int trunc_, int ix_, int iy_, int kx_)
     return "";
 }
 
+std::string HostTables::set_sigma(const double *hsg_in)
+{
+    if (!hsg_in) return "null hsg";
+    for (int k = 0; k <= kx; ++k) {
+        if (!(hsg_in[k] >= 0.0 && hsg_in[k] <= 1.0)) return "half levels must lie in [0, 1]";
+        if (k && !(hsg_in[k] > hsg_in[k - 1])) return "half levels must increase strictly";
+    }
+    for (int k = 0; k <= kx; ++k) hsg[k] = hsg_in[k];
+    make_sigma_derived(*this);
+    implicit_ready = false;
+    return "";
+}
+
 std::string HostTables::build_implicit(double dt)
 {
-    if (kx != 5 && kx != 7 && kx != 8) return "implicit solve needs kx in {5,7,8} (geometry.f90:42-48)";
+    if (!sigma_ready)
+        return "no sigma levels: the reference defines them for kx in {5,7,8} only (geometry.f90:42-48); "
+               "supply others with spdy_plan_set_sigma";
     const int sz = mx * nx, nl = mx + nx + 1;
-    const double kap = akap(), rgas = kap * kCp;
+    const double kap = kap32(), rgas = kap * kCp;
     const double rgam = rgas * kGammaLapse / (1000.0 * kGrav);
     for (int i = 0; i < sz; ++i) {
         dmp1[i] = 1.0 / (1.0 + dmp[i] * dt);
@@ -403,7 +457,8 @@ const double *HostTables::lookup(const std::string &name, int *count, std::vecto
         {"uvdym", &uvdym}, {"uvdyp", &uvdyp}, {"vddym", &vddym}, {"vddyp", &vddyp}, {"dmp", &dmp},
         {"dmpd", &dmpd}, {"dmps", &dmps}, {"dmp1", &dmp1}, {"dmp1d", &dmp1d}, {"dmp1s", &dmp1s},
         {"tref", &tref}, {"tref1", &tref1}, {"tref2", &tref2}, {"tref3", &tref3}, {"xc", &xc}, {"xd", &xd},
-        {"xj", &xj}, {"dhsx", &dhsx}, {"elz", &elz}};
+        {"xj", &xj}, {"dhsx", &dhsx}, {"elz", &elz}, {"xgeop1", &xgeop1}, {"xgeop2", &xgeop2}, {"corf", &corf},
+        {"tcorv", &tcorv}, {"qcorv", &qcorv}, {"coriol", &coriol}};
     for (const auto &e : ents)
         if (name == e.n) { *count = static_cast<int>(e.v->size()); return e.v->data(); }
     if (name == "ifac") {

@@ -223,6 +223,30 @@ class Spectral:
         """implicit.f90:36"""
         check(self.lib.spdy_implicit_init(self.h, float(dt)))
 
+    def set_sigma(self, hsg):
+        """Half levels hsg[kx+1] for a level count the reference defines no set for (geometry.f90:42-48)."""
+        hsg = np.ascontiguousarray(hsg, np.float64)
+        if hsg.shape != (self.kx + 1,):
+            raise ValueError("hsg must have kx+1 entries")
+        check(self.lib.spdy_plan_set_sigma(self.h, _p(hsg)))
+
+    def get_geopotential(self, t, phis):
+        """geopotential.f90:33 -- t [kx,nx,mx], phis [nx,mx] -> phi [kx,nx,mx]."""
+        t = np.ascontiguousarray(t, np.complex128); phis = np.ascontiguousarray(phis, np.complex128)
+        if t.shape != (self.kx,) + self.spec_shape or phis.shape != self.spec_shape:
+            raise ValueError("get_geopotential expects (kx,nx,mx), (nx,mx)")
+        phi = np.empty_like(t)
+        check(self.lib.spdy_geopotential(self.h, _p(t), _p(phis), _p(phi)))
+        return phi
+
+    def step_field(self, j1, dt, eps, wil, field, fdt):
+        """time_stepping.f90:121-167 step_field_2d/3d -- field [2,nlev,nx,mx] (or [2,nx,mx]), fdt [nlev,nx,mx] (or
+        [nx,mx]); returns the updated copies (field, fdt)."""
+        f = np.array(field, np.complex128, order="C"); d = np.array(fdt, np.complex128, order="C")
+        nlev = 1 if d.ndim == 2 else d.shape[0]
+        check(self.lib.spdy_step_field(self.h, nlev, int(j1), float(dt), float(eps), float(wil), _p(f), _p(d)))
+        return f, d
+
     def implicit_terms(self, divdt, tdt, psdt):
         """implicit.f90:168 (returns the updated copies)."""
         d = np.array(divdt, np.complex128, order="C")
@@ -309,6 +333,30 @@ class Spectral:
 
     def implicit_terms_dev(self, divdt, tdt, psdt):
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
+
+    def geopotential_dev(self, t, phis, phi):
+        check(self.lib.spdy_geopotential_dev(self.h, self._dp(t), self._dp(phis), self._dp(phi)))
+
+    def spectral_tendencies_dev(self, div, t, ps, phis, divdt, tdt, psdt, phi):
+        """tendencies.f90:242-293 -- div, t, ps: time level j2 of the prognostics; divdt, tdt, psdt in place; phi out."""
+        check(self.lib.spdy_spectral_tendencies_dev(self.h, *[self._dp(x) for x in (div, t, ps, phis, divdt, tdt, psdt, phi)]))
+
+    def hdiff_step_dev(self, vor, div, t, tr, tcorh, qcorh, sdrag, vordt, divdt, tdt, trdt):
+        """The diffusion block of step() (time_stepping.f90:62-96) in one launch; tendencies in place."""
+        dp = lambda x: self._dp(x) if x is not None else None
+        check(self.lib.spdy_hdiff_step_dev(self.h, dp(vor), dp(div), dp(t), dp(tr), dp(tcorh), dp(qcorh), float(sdrag),
+                                           dp(vordt), dp(divdt), dp(tdt), dp(trdt)))
+
+    def step_fields_dev(self, pairs, j1, dt, eps, wil):
+        """step_field_2d/3d for several prognostic arrays in one launch: pairs = [(field [2,nlev,nx,mx], fdt [nlev,nx,mx]), ...]."""
+        class Op(ctypes.Structure):
+            _fields_ = [("nlev", ctypes.c_int), ("field", ctypes.c_void_p), ("fdt", ctypes.c_void_p)]
+        arr = (Op * len(pairs))()
+        for o, (f, d) in zip(arr, pairs):
+            nlev = 1 if d.dim() == 2 else d.shape[0]
+            assert f.numel() == 2 * d.numel()
+            o.nlev, o.field, o.fdt = nlev, f.data_ptr(), d.data_ptr()
+        check(self.lib.spdy_step_fields_dev(self.h, len(pairs), ctypes.cast(arr, ctypes.c_void_p), int(j1), float(dt), float(eps), float(wil)))
 
     def hdiff_multi_dev(self, ops):
         """ops: up to 8 tuples (field, fdt_in, dmp_name, dmp1_name, out) -- the diffusion calls of one time step

@@ -39,14 +39,22 @@ def golden():
     return load
 
 
+# tag -> (trunc, ix, iy, kx): the stock builds and the other level counts (oracle/build_ref.sh variants)
+VARIANTS = {"t30": (30, 96, 24, 8), "t63": (63, 192, 48, 8), "t30k5": (30, 96, 24, 5), "t30k7": (30, 96, 24, 7),
+            "t63k16": (63, 192, 48, 16)}
+
+
 @pytest.fixture(scope="session")
 def oracle_factory():
-    from oracle.pyoracle import Oracle, RESOLUTIONS, build
+    from oracle.pyoracle import Oracle, build
+    import synth
     build()
     cache = {}
 
     def get(tag):
         if tag not in cache:
-            cache[tag] = Oracle(*RESOLUTIONS[tag])
+            cache[tag] = Oracle(*VARIANTS[tag])
+            if tag == "t63k16":                       # the reference has no 16-level sigma set (geometry.f90:42-48)
+                cache[tag].set_sigma(synth.SIGMA_L16)
         return cache[tag]
     return get

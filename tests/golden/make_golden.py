@@ -25,11 +25,49 @@ from oracle.pyoracle import Reference, build  # noqa: E402
 DTS = (1200.0, 2400.0, 4800.0)   # time_stepping.f90:15-23: initialize_implicit(dt/2, dt, 2dt), delt=2400
 
 
-def tail_inputs(kx, nx, mx):
-    """Seeded (divdt, tdt, psdt)-shaped inputs for implicit_terms / do_horizontal_diffusion."""
-    u = synth.splitmix64(99, 2 * (2 * kx + 1) * nx * mx).reshape(2 * kx + 1, nx, mx, 2) * 2 - 1
-    z = u[..., 0] + 1j * u[..., 1]
-    return z[:kx] * 1e-6, z[kx:2 * kx] * 1e-3, z[2 * kx] * 1e-5
+tail_inputs = synth.tail_inputs   # seeded (divdt, tdt, psdt)-shaped inputs for implicit_terms / do_horizontal_diffusion
+
+L16_SUB = (slice(None), slice(None, None, 5), slice(None, None, 3))   # the part of a [16,65,64] array kept for T63 L16
+
+
+def geop_inputs(kx, nx, mx):
+    """Seeded spectral temperature [kx,nx,mx] (~300) and surface geopotential [nx,mx] (~1000)."""
+    return synth.cfield((kx, nx, mx), 5, 300.0), synth.cfield((nx, mx), 6, 1000.0)
+
+
+def make_extra():
+    """ref_extra.npz: the reference builds with other level counts (oracle/build_ref.sh: kx = 5, 7 and the 16-level
+    T63 build that gets its half levels through the reference's public geometry variables) + get_geopotential."""
+    from oracle.pyoracle import Oracle
+    d = {}
+    for tag, sub in (("t30", None), ("t63", None), ("t30k5", None), ("t30k7", None), ("t63k16", L16_SUB)):
+        r = Reference(tag)
+        kx, nx, mx = r.kx, r.nx, r.mx
+        cut = (lambda a: a[sub]) if sub else (lambda a: a)
+        if tag == "t63k16":
+            # half levels in, derived level tables from the C oracle (bit-equal to the reference's own at kx = 5, 7, 8)
+            o = Oracle(r.trunc, r.ix, r.iy, kx)
+            o.set_sigma(synth.SIGMA_L16)
+            r.set_sigma(*[o.table(n) for n in ("hsg", "dhs", "fsg", "dhsr", "fsgr")])
+        d[tag + "_coriol"] = r.coriol()
+        d.update({tag + "_" + k: v for k, v in r.sigma().items()})
+        T, phis = geop_inputs(kx, nx, mx)
+        d[tag + "_geop"] = cut(r.geopotential(T, phis))
+        div, t, ps = tail_inputs(kx, nx, mx)
+        for dt in ((4800.0,) if tag.startswith("t63") else (1200.0, 4800.0)):
+            key = "%s_dt%d_" % (tag, int(dt))
+            r.tail_init(dt)
+            d.update({key + k: v for k, v in r.tref_tables().items()})
+            d.update({tag + "_" + k: v for k, v in r.corv().items()})
+            if tag in ("t30", "t63"):
+                continue                                  # their implicit/hdiff outputs are in ref_<tag>.npz
+            a, b, c = r.implicit_terms(div, t, ps)
+            d[key + "imp_div_out"], d[key + "imp_t_out"], d[key + "imp_ps_out"] = cut(a), cut(b), c
+            dm = r.dmp_tables()
+            d[key + "hdiff3d"] = cut(r.hdiff(t, div, dm["dmpd"], dm["dmp1d"]))
+    out = os.path.join(HERE, "ref_extra.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
 def make(tag, nb_grid, dts, imp_dts, lean):
@@ -96,3 +134,4 @@ if __name__ == "__main__":
     build(quiet=True)
     make("t30", nb_grid=2, dts=DTS, imp_dts=(1200.0, 4800.0), lean=False)
     make("t63", nb_grid=1, dts=(4800.0,), imp_dts=(4800.0,), lean=True)
+    make_extra()

@@ -54,3 +54,24 @@ def relerr(x, ref):
     d = np.max(np.abs(x - ref)) if x.size else 0.0
     s = np.max(np.abs(ref)) if ref.size else 0.0
     return float(d / s) if s > 0 else float(d)
+
+
+# A 16-level half-sigma set for the T63 L16 configuration (BASELINE.json config 5).  The reference defines sigma
+# levels for kx = 5, 7, 8 only (geometry.f90:42-48); this is its 8-level set with every layer split in two, written
+# like the reference's literals (float32 values widened to double).
+SIGMA_L16 = np.array([0.000, 0.025, 0.050, 0.095, 0.140, 0.200, 0.260, 0.340, 0.420, 0.510, 0.600, 0.685, 0.770, 0.835,
+                      0.900, 0.950, 1.000], np.float32).astype(np.float64)
+
+
+def tail_inputs(kx, nx, mx, seed=99):
+    """Seeded (divdt, tdt, psdt)-shaped complex inputs: [kx,nx,mx] x 1e-6, [kx,nx,mx] x 1e-3, [nx,mx] x 1e-5."""
+    u = splitmix64(seed, 2 * (2 * kx + 1) * nx * mx).reshape(2 * kx + 1, nx, mx, 2) * 2 - 1
+    z = u[..., 0] + 1j * u[..., 1]
+    return z[:kx] * 1e-6, z[kx:2 * kx] * 1e-3, z[2 * kx] * 1e-5
+
+
+def cfield(shape, seed, scale=1.0):
+    """Seeded complex array of the given shape, U(-1,1) + i U(-1,1), times scale."""
+    n = int(np.prod(shape))
+    u = splitmix64(seed, 2 * n).reshape(tuple(shape) + (2,)) * 2 - 1
+    return (u[..., 0] + 1j * u[..., 1]) * scale

@@ -138,3 +138,109 @@ def test_against_live_reference(tag, oracle_factory):
     assert 1e-6 < err < 5e-3
     out = o.roundtrip_loop(G[:2]); ref = r.roundtrip_loop(G[:2])
     close(out, ref)
+
+
+EXTRA = ("t30", "t63", "t30k5", "t30k7", "t63k16")
+
+
+@pytest.mark.parametrize("tag", EXTRA)
+def test_other_level_counts_and_geopotential(tag, golden, oracle_factory):
+    """ref_extra.npz: flang builds of the reference with kx = 5, 7 (geometry.f90:42-48) and kx = 16 (half levels
+    supplied through the reference's public geometry variables), plus get_geopotential (geopotential.f90:33-57),
+    coriol (geometry.f90:89) and tcorv/qcorv (horizontal_diffusion.f90:70-82) at every level count."""
+    from golden.make_golden import geop_inputs, L16_SUB
+    g, o = golden("extra"), oracle_factory(tag)
+    cut = (lambda a: a[L16_SUB]) if tag == "t63k16" else (lambda a: a)
+    for name in ("hsg", "dhs", "fsg", "dhsr", "fsgr", "coriol", "tcorv", "qcorv"):
+        assert np.array_equal(o.table(name), g[tag + "_" + name]), name
+    T, phis = geop_inputs(o.kx, o.nx, o.mx)
+    assert np.array_equal(cut(o.geopotential(T, phis)), g[tag + "_geop"])
+    div, t, ps = tail_inputs(o.kx, o.nx, o.mx)
+    for dt in (1200.0, 4800.0):
+        key = "%s_dt%d_" % (tag, int(dt))
+        if key + "tref" not in g.files:
+            continue
+        o.tail_init(dt)
+        for name in ("tref", "tref2", "tref3"):
+            assert np.array_equal(o.table(name), g[key + name]), name
+        if key + "imp_div_out" in g.files:
+            a, b, c = o.implicit_terms(div, t, ps)
+            close(cut(a), g[key + "imp_div_out"]); close(cut(b), g[key + "imp_t_out"]); close(c, g[key + "imp_ps_out"])
+            close(cut(o.hdiff(t, div, o.table("dmpd").reshape(o.nx, o.mx), o.table("dmp1d").reshape(o.nx, o.mx))), g[key + "hdiff3d"])
+
+
+@pytest.mark.parametrize("tag", ("t30k5", "t30k7", "t63k16"))
+def test_other_level_counts_live(tag, oracle_factory):
+    from oracle.pyoracle import Reference
+    if not Reference.available(tag):
+        pytest.skip("oracle/_ref not built")
+    r, o = Reference(tag), oracle_factory(tag)
+    if tag == "t63k16":
+        r.set_sigma(*[o.table(n) for n in ("hsg", "dhs", "fsg", "dhsr", "fsgr")])
+    r.tail_init(2400.0); o.tail_init(2400.0)
+    div, t, ps = synth.tail_inputs(o.kx, o.nx, o.mx, seed=1234)
+    for x, y in zip(o.implicit_terms(div, t, ps), r.implicit_terms(div, t, ps)):
+        close(x, y)
+    T, phis = synth.cfield((o.kx, o.nx, o.mx), 77, 250.0), synth.cfield((o.nx, o.mx), 78, 500.0)
+    close(o.geopotential(T, phis), r.geopotential(T, phis))
+
+
+def test_step_restatements_selfconsistent(oracle_factory):
+    """get_spectral_tendencies, the diffusion block and step_field cannot be pinned (their modules need NetCDF);
+    check the restatements against independent NumPy readings of the same source lines, and against the pinned
+    pieces they are built from."""
+    o = oracle_factory("t30")
+    o.tail_init(4800.0)
+    kx, nx, mx = o.kx, o.nx, o.mx
+    shp = (kx, nx, mx)
+    # --- step_field_2d (time_stepping.f90:142-167)
+    rob, wil, dt = float(np.float32(0.05)), float(np.float32(0.53)), 4800.0
+    F = synth.cfield((2,) + shp, 11); D = synth.cfield(shp, 12, 1e-4)
+    trf = o.table("trfilt").reshape(nx, mx)
+    for j1, eps in ((1, 0.0), (2, rob)):
+        out, fdt = o.step_field(j1, dt, eps, wil, F, D)
+        fd = D * trf
+        o1, o2 = F[0].copy(), F[1].copy()
+        fnew = o1 + dt * fd
+        oj = o1 if j1 == 1 else o2
+        n1 = oj + wil * eps * (o1 - 2 * oj + fnew)
+        oj2 = n1 if j1 == 1 else o2
+        n2 = fnew - (1.0 - wil) * eps * (n1 - 2.0 * oj2 + fnew)
+        assert synth.relerr(out[0], n1) < 1e-15 and synth.relerr(out[1], n2) < 1e-15 and np.array_equal(fdt, fd)
+    # --- diffusion block (time_stepping.f90:62-96) from the pinned do_horizontal_diffusion
+    vor, div, t, tr = (synth.cfield(shp, 20 + i) for i in range(4))
+    vdt, ddt, tdt, qdt = (synth.cfield(shp, 30 + i, 1e-5) for i in range(4))
+    tcorh, qcorh = synth.cfield((nx, mx), 40), synth.cfield((nx, mx), 41)
+    sdrag = 1.0 / (float(np.float32(24.0 * 30.0)) * 3600.0)
+    T = {n: o.table(n).reshape(nx, mx) for n in ("dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s")}
+    a, b, c, d = o.hdiff_step(vor, div, t, tr, tcorh, qcorh, sdrag, vdt, ddt, tdt, qdt)
+    hd = o.hdiff
+    ra = hd(vor, vdt, T["dmp"], T["dmp1"]); rb = hd(div, ddt, T["dmpd"], T["dmp1d"])
+    ctmp = t + tcorh[None] * o.table("tcorv")[:, None, None]
+    rc = hd(ctmp, tdt, T["dmp"], T["dmp1"])
+    ra[0, :, 0] -= sdrag * vor[0, :, 0]; rb[0, :, 0] -= sdrag * div[0, :, 0]
+    ra = hd(vor, ra, T["dmps"], T["dmp1s"]); rb = hd(div, rb, T["dmps"], T["dmp1s"]); rc = hd(ctmp, rc, T["dmps"], T["dmp1s"])
+    rd = hd(tr + qcorh[None] * o.table("qcorv")[:, None, None], qdt, T["dmpd"], T["dmp1d"])
+    for x, y in ((a, ra), (b, rb), (c, rc), (d, rd)):
+        assert synth.relerr(x, y) < 1e-15
+    # --- get_spectral_tendencies (tendencies.f90:242-293)
+    ps, phis = synth.cfield((nx, mx), 50, 0.1), synth.cfield((nx, mx), 51, 1000.0)
+    psdt = synth.cfield((nx, mx), 52, 1e-6)
+    tt = synth.cfield(shp, 53, 300.0)
+    A, B, C, phi = o.spectral_tendencies(div, tt, ps, phis, ddt, tdt, psdt)
+    dhs, dhsr = o.table("dhs"), o.table("dhsr")
+    tref, tref2, tref3 = o.table("tref"), o.table("tref2"), o.table("tref3")
+    dmean = sum(div[k] * dhs[k] for k in range(kx))
+    rps = psdt - dmean; rps[0, 0] = 0
+    sig = np.zeros((kx + 1, nx, mx), complex); dumk = np.zeros_like(sig)
+    for k in range(kx - 1):
+        sig[k + 1] = sig[k] - dhs[k] * (div[k] - dmean)
+    for k in range(1, kx):
+        dumk[k] = sig[k] * (tref[k] - tref[k - 1])
+    rt = np.stack([tdt[k] - (dumk[k + 1] + dumk[k]) * dhsr[k] + tref3[k] * (sig[k + 1] + sig[k]) - tref2[k] * dmean for k in range(kx)])
+    rphi = o.geopotential(tt, phis)
+    rgas = float(np.float32(2.0) / np.float32(7.0)) * 1004.0
+    rdiv = np.stack([ddt[k] - o.laplacian(rphi[k] + rgas * tref[k] * ps) for k in range(kx)])
+    assert np.array_equal(phi, rphi)
+    for x, y in ((A, rdiv), (B, rt), (C, rps)):
+        assert synth.relerr(x, y) < 1e-14
