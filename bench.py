@@ -121,6 +121,7 @@ def main():
     nb = args.batch or (6144 if args.res == "t30" else 1536)
     sp = s.Spectral(args.res, kx=8, max_batch=nb, device=local)
     # the plan keeps its own (non-default) stream; torch.cuda.synchronize() below covers every stream of the device
+    sp.use_own_stream()
     sp.set_fused(args.fused)
 
     # synthetic white-noise grids: 64 seeded templates tiled and rescaled per field so

@@ -154,7 +154,62 @@ module spdy_c
             complex(c_double_complex), intent(inout) :: divdt(*), tdt(*), psdt(*)
             integer(c_int) :: rc
         end function
+        function spdy_plan_set_sigma(plan, hsg) bind(C, name="spdy_plan_set_sigma") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: plan
+            real(c_double), intent(in) :: hsg(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_geopotential(plan, t, phis, phi) bind(C, name="spdy_geopotential") result(rc)
+            import :: c_int, c_ptr, c_double_complex
+            type(c_ptr), value :: plan
+            complex(c_double_complex), intent(in) :: t(*), phis(*)
+            complex(c_double_complex), intent(out) :: phi(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_step_field(plan, nlev, j1, dt, eps, wil, field, fdt) bind(C, name="spdy_step_field") result(rc)
+            import :: c_int, c_ptr, c_double, c_double_complex
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nlev, j1
+            real(c_double), value :: dt, eps, wil
+            complex(c_double_complex), intent(inout) :: field(*), fdt(*)
+            integer(c_int) :: rc
+        end function
+        ! ---- multi-GPU (one process per GPU): level all-gather over RCCL for the level-sharded implicit solve
+        function spdy_comm_unique_id(id) bind(C, name="spdy_comm_unique_id") result(rc)
+            import :: c_int, c_char
+            character(kind=c_char), intent(out) :: id(128)
+            integer(c_int) :: rc
+        end function
+        function spdy_comm_create(plan, nranks, rank, id, comm) bind(C, name="spdy_comm_create") result(rc)
+            import :: c_int, c_ptr, c_char
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nranks, rank
+            character(kind=c_char), intent(in) :: id(128)
+            type(c_ptr), intent(out) :: comm
+            integer(c_int) :: rc
+        end function
+        function spdy_comm_destroy(comm) bind(C, name="spdy_comm_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm
+            integer(c_int) :: rc
+        end function
+        function spdy_comm_level_range(comm, nlev, lo, hi) bind(C, name="spdy_comm_level_range") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm
+            integer(c_int), value :: nlev
+            integer(c_int), intent(out) :: lo, hi
+            integer(c_int) :: rc
+        end function
+        ! device pointers (type(c_ptr) values obtained from the host's own HIP allocations)
+        function spdy_implicit_terms_sharded_dev(comm, divdt, tdt, psdt) bind(C, name="spdy_implicit_terms_sharded_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm, divdt, tdt, psdt
+            integer(c_int) :: rc
+        end function
     end interface
+
+    integer(c_int), parameter :: SPDY_DEVICE_AUTO = -2_c_int   !! $SPDY_DEVICE, else the launcher's local rank (include/spdy.h)
 
 contains
     !> The reference has no status returns (it `stop`s on fatal errors, e.g. matrix_inversion.f90:26);

@@ -36,8 +36,9 @@ contains
     subroutine initialize_spectral
         integer(c_int) :: rc
         if (c_associated(spectral_plan)) return
+        ! one process per GPU: the device is $SPDY_DEVICE, else the launcher's local rank, else 0 (SPDY_DEVICE_AUTO)
         rc = spdy_plan_create(int(trunc, c_int), int(ix, c_int), int(iy, c_int), int(kx, c_int), &
-                            & int(max(8*kx, 64), c_int), 0_c_int, spectral_plan)
+                            & int(max(8*kx, 64), c_int), SPDY_DEVICE_AUTO, spectral_plan)
         call spdy_check(rc, 'spdy_plan_create')
         rc = spdy_get_table(spectral_plan, 'el2'//c_null_char, el2, int(mx*nx, c_int))
         call spdy_check(rc, 'spdy_get_table(el2)')

@@ -1,15 +1,17 @@
-!> Test driver for the drop-in `spectral` module: reads seeded inputs written by
+!> Test driver for the drop-in modules (spectral, horizontal_diffusion, implicit, geopotential): reads seeded inputs written by
 !  tests/test_fortran_dropin.py, calls the reference-named API exactly as the model would, and
 !  writes the results back for the test to compare.
 program dropin_driver
     use types, only: p
     use params
     use spectral
-    use spdy_tail
+    use horizontal_diffusion
+    use implicit
+    use geopotential
     implicit none
     complex(p) :: s(mx,nx,2), so(mx,nx), u(mx,nx), v(mx,nx), vor(mx,nx), div(mx,nx), dx(mx,nx), dy(mx,nx)
     complex(p) :: sk(mx,nx,kx), tk(mx,nx,kx), ps(mx,nx), hk(mx,nx,kx), slev(mx,nx,kx)
-    real(p) :: g(ix,il,2), go(ix,il), dmp(mx,nx), dmp1(mx,nx), glev(ix,il,kx), glev2(ix,il,kx)
+    real(p) :: g(ix,il,2), go(ix,il), dmp_in(mx,nx), dmp1_in(mx,nx), glev(ix,il,kx), glev2(ix,il,kx)
     complex(p) :: slev2(mx,nx,kx)
     integer :: kc(kx), k
     character(len=512) :: fin, fout
@@ -17,7 +19,7 @@ program dropin_driver
     call get_command_argument(1, fin)
     call get_command_argument(2, fout)
     open(10, file=trim(fin), access='stream', form='unformatted', status='old')
-    read(10) s, g, sk, tk, ps, dmp, dmp1
+    read(10) s, g, sk, tk, ps, dmp_in, dmp1_in
     close(10)
 
     call initialize_spectral
@@ -39,9 +41,15 @@ program dropin_driver
     end do
     call spec_to_grid_levels(kx, sk, kc, glev); write(11) glev
     call grid_to_spec_levels(kx, glev, slev);   write(11) slev
-    hk = spdy_do_horizontal_diffusion(tk, sk, dmp, dmp1); write(11) hk
-    call spdy_initialize_implicit(real(4800, p))
-    call spdy_implicit_terms_f(sk, tk, ps); write(11) sk, tk, ps
+    ! the reference's own init order (initialization.f90:19-20, time_stepping.f90:12-24) and calls
+    call initialize_geopotential
+    call initialize_horizontal_diffusion
+    call initialize_implicit(real(4800, p))
+    write(11) dmp, dmpd, dmps, dmp1, dmp1d, dmp1s, tcorv, qcorv, tref, tref2, tref3
+    hk = do_horizontal_diffusion(tk, sk, dmp_in, dmp1_in); write(11) hk          ! 3-D specific
+    so = do_horizontal_diffusion(ps, sk(:,:,1), dmps, dmp1s); write(11) so       ! 2-D specific, module tables
+    hk = get_geopotential(tk, ps); write(11) hk
+    call implicit_terms(sk, tk, ps); write(11) sk, tk, ps
     ! operator + transform sequences over a level stack (one call each)
     call uvspec_to_grid_levels(kx, sk, tk, glev, glev2); write(11) glev, glev2
     call grad_to_grid_levels(kx, sk, glev, glev2);       write(11) glev, glev2

@@ -16,4 +16,5 @@ module params
     integer, parameter :: trunc = 30, ix = 96, iy = 24
 #endif
     integer, parameter :: il = 2*iy, kx = 8, nx = trunc + 2, mx = trunc + 1
+    integer, parameter :: nsteps = 36          ! params.f90:30 (read by initialize_horizontal_diffusion)
 end module

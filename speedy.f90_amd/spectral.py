@@ -10,7 +10,7 @@ arrays (axes reversed):
 
 Leading dimensions are the batch (e.g. the kx levels of a (mx,nx,kx) array).  Host methods
 accept/return NumPy arrays; *_dev methods take torch CUDA tensors (device memory stays where
-it is, kernels run on torch's current stream).
+it is; kernels run on torch's current stream unless use_own_stream() was called).
 """
 import ctypes
 
@@ -258,9 +258,27 @@ class Spectral:
         return d, t, p
 
     # ------------------------------------------------------------------ device-resident batch (torch tensors)
+    # Stream policy of the device-resident (`*_dev`) methods.  Default: follow torch -- before every call the plan is
+    # switched to torch's current stream, so kernels are ordered with the torch ops that produce/consume the tensors
+    # (torch's legacy default stream maps to the plan's own blocking stream, which HIP orders against the default
+    # stream).  use_own_stream(): the plan keeps its own stream (bench.py, graph replay loops); the caller synchronises.
     def use_torch_stream(self):
+        self._follow = True
+        self._sync_stream()
+
+    def use_own_stream(self):
+        self._follow = False
+        self._cur_stream = 0
+        check(self.lib.spdy_plan_set_stream(self.h, None))
+
+    def _sync_stream(self):
+        if not getattr(self, "_follow", True):
+            return
         import torch
-        check(self.lib.spdy_plan_set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        h = torch.cuda.current_stream().cuda_stream
+        if h != getattr(self, "_cur_stream", 0):
+            check(self.lib.spdy_plan_set_stream(self.h, ctypes.c_void_p(h) if h else None))
+            self._cur_stream = h
 
     KERNEL_KINDS = ("legendre_inv", "fourier_inv", "fourier_dir", "legendre_dir", "s2g_fused", "g2s_fused")
 
@@ -282,6 +300,10 @@ class Spectral:
         check(self.lib.spdy_plan_synchronize(self.h))
 
     def graph_capture(self):
+        self._sync_stream()
+        return self._graph_capture()
+
+    def _graph_capture(self):
         """Context manager: record the ``*_dev`` calls made inside it (nothing runs) and return a
         :class:`Graph` whose ``launch()`` replays them as one HIP graph launch on the plan's stream::
 
@@ -298,57 +320,70 @@ class Spectral:
 
     def spec_to_grid_dev(self, d_spec, d_grid, kcos=1, d_kcos=None):
         """d_spec: [nb, nx, mx] complex128 (or [nb,nx,mx,2] float64) CUDA tensor; d_grid: [nb, il, ix] float64."""
+        self._sync_stream()
         nb = d_grid.shape[0]
         check(self.lib.spdy_spec_to_grid_dev(self.h, nb, self._dp(d_spec), self._dp(d_kcos) if d_kcos is not None else None,
                                              int(kcos), self._dp(d_grid)))
 
     def grid_to_spec_dev(self, d_grid, d_spec):
+        self._sync_stream()
         nb = d_grid.shape[0]
         check(self.lib.spdy_grid_to_spec_dev(self.h, nb, self._dp(d_grid), self._dp(d_spec)))
 
     def uvspec_dev(self, vor, div, u, v):
+        self._sync_stream()
         check(self.lib.spdy_uvspec_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(u), self._dp(v)))
 
     def vdspec_dev(self, ug, vg, vor, div, kcos=2):
+        self._sync_stream()
         check(self.lib.spdy_vdspec_dev(self.h, ug.shape[0], self._dp(ug), self._dp(vg), self._dp(vor), self._dp(div), int(kcos)))
 
     def uvspec_to_grid_dev(self, vor, div, ug, vg, kcos=2):
         """uvspec followed by spec_to_grid(., kcos) of both results (tendencies.f90:98-100), one pass at T30."""
+        self._sync_stream()
         check(self.lib.spdy_uvspec_to_grid_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(ug), self._dp(vg), int(kcos)))
 
     def grad_to_grid_dev(self, psi, gx, gy, kcos=2):
         """grad followed by spec_to_grid(., kcos) of both results (tendencies.f90:121-123), one pass at T30."""
+        self._sync_stream()
         check(self.lib.spdy_grad_to_grid_dev(self.h, psi.shape[0], self._dp(psi), self._dp(gx), self._dp(gy), int(kcos)))
 
     def inverse_batch_dev(self, vor, div, ug, vg, spec, grid, kcos_pairs=2, kcos=1, d_kcos=None):
         """uvspec + spec_to_grid(., kcos_pairs) of the (vor, div) pairs and spec_to_grid of `spec` in one launch."""
+        self._sync_stream()
         check(self.lib.spdy_inverse_batch_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(ug), self._dp(vg), int(kcos_pairs),
                                               spec.shape[0], self._dp(spec), self._dp(d_kcos) if d_kcos is not None else None, int(kcos),
                                               self._dp(grid)))
 
     def direct_batch_dev(self, ug, vg, vor, div, grid, spec, kcos=2):
         """vdspec of the (ug, vg) pairs and grid_to_spec of `grid` in one launch (a model step's direct batch)."""
+        self._sync_stream()
         check(self.lib.spdy_direct_batch_dev(self.h, ug.shape[0], self._dp(ug), self._dp(vg), self._dp(vor), self._dp(div), int(kcos),
                                              grid.shape[0], self._dp(grid), self._dp(spec)))
 
     def implicit_terms_dev(self, divdt, tdt, psdt):
+        self._sync_stream()
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
 
     def geopotential_dev(self, t, phis, phi):
+        self._sync_stream()
         check(self.lib.spdy_geopotential_dev(self.h, self._dp(t), self._dp(phis), self._dp(phi)))
 
     def spectral_tendencies_dev(self, div, t, ps, phis, divdt, tdt, psdt, phi):
         """tendencies.f90:242-293 -- div, t, ps: time level j2 of the prognostics; divdt, tdt, psdt in place; phi out."""
+        self._sync_stream()
         check(self.lib.spdy_spectral_tendencies_dev(self.h, *[self._dp(x) for x in (div, t, ps, phis, divdt, tdt, psdt, phi)]))
 
     def hdiff_step_dev(self, vor, div, t, tr, tcorh, qcorh, sdrag, vordt, divdt, tdt, trdt):
         """The diffusion block of step() (time_stepping.f90:62-96) in one launch; tendencies in place."""
+        self._sync_stream()
         dp = lambda x: self._dp(x) if x is not None else None
         check(self.lib.spdy_hdiff_step_dev(self.h, dp(vor), dp(div), dp(t), dp(tr), dp(tcorh), dp(qcorh), float(sdrag),
                                            dp(vordt), dp(divdt), dp(tdt), dp(trdt)))
 
     def step_fields_dev(self, pairs, j1, dt, eps, wil):
         """step_field_2d/3d for several prognostic arrays in one launch: pairs = [(field [2,nlev,nx,mx], fdt [nlev,nx,mx]), ...]."""
+        self._sync_stream()
         class Op(ctypes.Structure):
             _fields_ = [("nlev", ctypes.c_int), ("field", ctypes.c_void_p), ("fdt", ctypes.c_void_p)]
         arr = (Op * len(pairs))()
@@ -361,6 +396,7 @@ class Spectral:
     def hdiff_multi_dev(self, ops):
         """ops: up to 8 tuples (field, fdt_in, dmp_name, dmp1_name, out) -- the diffusion calls of one time step
         (time_stepping.f90:63-96) in one launch."""
+        self._sync_stream()
         class Op(ctypes.Structure):
             _fields_ = [("nlev", ctypes.c_int), ("field", ctypes.c_void_p), ("fdt_in", ctypes.c_void_p),
                         ("d_dmp", ctypes.c_void_p), ("d_dmp1", ctypes.c_void_p), ("fdt_out", ctypes.c_void_p)]
@@ -373,6 +409,7 @@ class Spectral:
         check(self.lib.spdy_hdiff_multi_dev(self.h, len(ops), ctypes.cast(arr, ctypes.c_void_p)))
 
     def hdiff_dev(self, field, fdt_in, dmp_name, dmp1_name, out):
+        self._sync_stream()
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         check(self.lib.spdy_device_table(self.h, dmp_name.encode(), ctypes.byref(a)))
         check(self.lib.spdy_device_table(self.h, dmp1_name.encode(), ctypes.byref(b)))

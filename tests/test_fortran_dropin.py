@@ -1,6 +1,6 @@
-"""The Fortran host side: the drop-in `spectral` module (speedy.f90_amd/fortran/spectral.f90) that keeps the
-reference's public names and signatures (spectral.f90:8-11) over the C ABI.  A flang-built driver calls
-it exactly as the model would; results are compared with the oracle at 1e-12."""
+"""The Fortran host side: the drop-in modules `spectral`, `horizontal_diffusion`, `implicit`, `geopotential`
+(speedy.f90_amd/fortran/) that keep the reference's module names, public names and signatures over the C ABI.
+A flang-built driver calls them exactly as the model would; results are compared with the oracle at 1e-12."""
 import os
 import subprocess
 
@@ -9,7 +9,7 @@ import pytest
 
 import synth
 from conftest import ROOT, TOL
-from golden.make_golden import tail_inputs
+from synth import tail_inputs
 
 FDIR = os.path.join(ROOT, "speedy.f90_amd", "fortran")
 
@@ -28,6 +28,28 @@ def test_fortran_sources_keep_reference_api():
     assert "function spec_to_grid(vorm, kcos) result(vorg)" in src
     assert "function grid_to_spec(vorg) result(vorm)" in src
     assert "bind(c" in open(os.path.join(FDIR, "spdy_c.f90")).read().lower()
+    # the tail modules: reference module names and full public sets (horizontal_diffusion.f90:10-11, implicit.f90:10-11,
+    # geopotential.f90:11)
+    for mod, names in (("horizontal_diffusion", ("initialize_horizontal_diffusion", "do_horizontal_diffusion", "dmp", "dmpd", "dmps",
+                                                 "dmp1", "dmp1d", "dmp1s", "tcorv", "qcorv", "tcorh", "qcorh")),
+                       ("implicit", ("initialize_implicit", "implicit_terms", "tref", "tref2", "tref3")),
+                       ("geopotential", ("initialize_geopotential", "get_geopotential"))):
+        src = open(os.path.join(FDIR, mod + ".f90")).read().lower()
+        assert "module " + mod in src
+        head = src.split("contains")[0]
+        pub = " ".join(l for l in head.split("\n") if l.strip().startswith("public"))
+        for name in names:
+            assert name in pub, (mod, name)
+
+
+def test_reference_callers_resolve_against_dropins():
+    """Build container only: compile the drop-ins against the reference's own types/params and check its callers'
+    `use ..., only:` lists (and two whole caller files) against them (fortran/check_reference_callers.sh)."""
+    if not os.path.isdir("/root/reference/source") or not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
+        pytest.skip("needs /root/reference and flang (build container)")
+    r = subprocess.run([os.path.join(FDIR, "check_reference_callers.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "compile unchanged against the drop-in" in r.stdout
 
 
 @pytest.mark.parametrize("tag", ["t30", "t63"])
@@ -93,7 +115,14 @@ def test_dropin_module_vs_oracle(tag, tmp_path, oracle_factory):
     slev = take((kx,) + sp, True)
     for k in range(kx):
         ok(slev[k], o.grid_to_spec(glev[k]))
+    # module tables filled by initialize_horizontal_diffusion / initialize_implicit (public in the reference)
+    for name in ("dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s"):
+        assert np.array_equal(take(sp, False), o.table(name).reshape(sp)), name
+    for name in ("tcorv", "qcorv", "tref", "tref2", "tref3"):
+        assert np.array_equal(take((kx,), False), o.table(name)), name
     ok(take((kx,) + sp, True), o.hdiff(tk, sk, dmp, dmp1))
+    ok(take(sp, True), o.hdiff(ps, sk[0], o.table("dmps").reshape(sp), o.table("dmp1s").reshape(sp)))
+    ok(take((kx,) + sp, True), o.geopotential(tk, ps))
     rd, rt, rp = o.implicit_terms(sk, tk, ps)
     ok(take((kx,) + sp, True), rd); ok(take((kx,) + sp, True), rt); ok(take(sp, True), rp)
     # level-stack sequences in one call each; inputs: the *updated* sk, tk written back by implicit_terms above

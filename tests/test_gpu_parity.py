@@ -9,7 +9,7 @@ import pytest
 
 import synth
 from conftest import TOL
-from golden.make_golden import tail_inputs
+from synth import tail_inputs
 
 pytestmark = pytest.mark.gpu
 TAGS = ("t30", "t63")
@@ -236,20 +236,55 @@ def test_device_ops_and_profile(oracle_factory):
     sp.close()
 
 
-@pytest.mark.parametrize("kx", [5, 7])
-def test_tail_other_level_counts(kx):
-    """The reference's other sigma-level sets (geometry.f90:42-48: kx = 5, 7).  The flang build of the reference is
-    fixed at kx = 8 (params.f90), so these are checked against the C restatement only (parity unpinned for them)."""
+@pytest.mark.parametrize("tag", ["t30k5", "t30k7", "t63k16"])
+def test_tail_other_level_counts(tag, golden, oracle_factory):
+    """The reference's other sigma-level sets (geometry.f90:42-48: kx = 5, 7) and the 16-level T63 configuration
+    (BASELINE config 5; half levels supplied with spdy_plan_set_sigma), against golden outputs of flang builds of the
+    reference at those level counts (oracle/build_ref.sh, tests/golden/ref_extra.npz)."""
     import speedy_f90_amd as s
-    from oracle.pyoracle import Oracle
-    o = Oracle(30, 96, 24, kx)
-    sp = s.Spectral("t30", kx=kx, max_batch=16, device=0)
+    from conftest import VARIANTS
+    from golden.make_golden import L16_SUB, geop_inputs
+    g, o = golden("extra"), oracle_factory(tag)
+    trunc, ix, iy, kx = VARIANTS[tag]
+    sp = s.Spectral((trunc, ix, iy), kx=kx, max_batch=2 * kx, device=0)
+    cut = (lambda a: a[L16_SUB]) if tag == "t63k16" else (lambda a: a)
+    if tag == "t63k16":
+        with pytest.raises(s.SpdyError):                  # no sigma levels yet: refused, not guessed
+            sp.initialize_implicit(4800.0)
+        sp.set_sigma(synth.SIGMA_L16)
+    for name in ("hsg", "dhs", "fsg", "dhsr", "fsgr", "tcorv", "qcorv"):
+        assert np.array_equal(sp.table(name), g[tag + "_" + name]), name
+    d, t, p = tail_inputs(kx, sp.nx, sp.mx)
     for dt in (1200.0, 4800.0):
-        o.tail_init(dt); sp.initialize_implicit(dt)
-        d, t, p = tail_inputs(kx, sp.nx, sp.mx)
-        rd, rt, rp = o.implicit_terms(d, t, p)
+        key = "%s_dt%d_" % (tag, int(dt))
+        if key + "imp_div_out" not in g.files:
+            continue
+        sp.initialize_implicit(dt); o.tail_init(dt)
         gd, gt, gp = sp.implicit_terms(d, t, p)
+        ok(cut(gd), g[key + "imp_div_out"]); ok(cut(gt), g[key + "imp_t_out"]); ok(gp, g[key + "imp_ps_out"])
+        rd, rt, rp = o.implicit_terms(d, t, p)            # the whole arrays against the (pinned) oracle
         ok(gd, rd); ok(gt, rt); ok(gp, rp)
         dmp, dmp1 = o.table("dmpd").reshape(sp.nx, sp.mx), o.table("dmp1d").reshape(sp.nx, sp.mx)
-        ok(sp.do_horizontal_diffusion(d, t, dmp, dmp1), o.hdiff(d, t, dmp, dmp1))
+        ok(cut(sp.do_horizontal_diffusion(t, d, dmp, dmp1)), g[key + "hdiff3d"])
+    T, phis = geop_inputs(kx, sp.nx, sp.mx)
+    ok(cut(sp.get_geopotential(T, phis)), g[tag + "_geop"])
     sp.close()
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_geopotential_vs_golden(tag, plans, golden):
+    from golden.make_golden import geop_inputs
+    sp = plans(tag)
+    T, phis = geop_inputs(sp.kx, sp.nx, sp.mx)
+    ok(sp.get_geopotential(T, phis), golden("extra")[tag + "_geop"])
+
+
+def test_kcos_other_values_mean_cosgr(plans, golden):
+    """fourier.f90:47-51: kcos == 1 is plain, ANY other value multiplies by cosgr -- also in the fused entry points."""
+    g, sp = golden("t30"), plans("t30", fused=1)
+    S = g["S"][:2]
+    for kc in (0, 2, 3, -1):
+        ok(sp.spec_to_grid(S, kc), g["s2g2"])
+        ug, vg = sp.uvspec_to_grid(S[0], S[1], kc)
+        ug2, vg2 = sp.uvspec_to_grid(S[0], S[1], 2)
+        assert np.array_equal(ug, ug2) and np.array_equal(vg, vg2)

@@ -1,0 +1,191 @@
+"""GPU: the device-resident spectral side of a time step and the captured model-step graph
+(BASELINE.json config 5: T63 L16 with horizontal diffusion + implicit solve, hipGraph-captured).
+
+Checker: the C oracle.  implicit_terms, do_horizontal_diffusion, get_geopotential and all transforms/operators in it
+are pinned to flang builds of the reference (also at 16 levels); get_spectral_tendencies, the diffusion block of
+step() and step_field are restatements of tendencies.f90:242-293 / time_stepping.f90:62-167, which cannot be compiled
+here (NetCDF chain) -- PARITY UNPINNED for those three, cross-checked against NumPy readings of the same lines in
+tests/test_oracle_golden.py::test_step_restatements_selfconsistent."""
+import numpy as np
+import pytest
+
+import synth
+from conftest import TOL, VARIANTS
+
+pytestmark = pytest.mark.gpu
+
+ROB, WIL = float(np.float32(0.05)), float(np.float32(0.53))          # params.f90:32-33 (float32 literals widened)
+SDRAG = 1.0 / (float(np.float32(24.0 * 30.0)) * 3600.0)              # time_stepping.f90:77, dynamical_constants.f90:22
+
+
+def ok(x, ref, tol=TOL):
+    assert x.shape == ref.shape
+    err = synth.relerr(x, ref)
+    assert err <= tol, err
+
+
+def make_plan(tag, max_batch):
+    import speedy_f90_amd as s
+    trunc, ix, iy, kx = VARIANTS[tag]
+    sp = s.Spectral((trunc, ix, iy), kx=kx, max_batch=max_batch, device=0)
+    if tag == "t63k16":
+        sp.set_sigma(synth.SIGMA_L16)
+    return sp
+
+
+def state(sp, seed):
+    """Band-limited prognostics [2, kx, nx, mx] (both time levels) and a few (nx, mx) fields."""
+    kx, nx, mx = sp.kx, sp.nx, sp.mx
+
+    def prog(first, scale):
+        return (synth.spectra(2 * kx, sp.trunc, first=first) * scale).reshape(2, kx, nx, mx)
+    st = {"vor": prog(seed, 1e-4), "div": prog(seed + 100, 1e-5), "t": prog(seed + 200, 30.0), "tr": prog(seed + 300, 1e-2)}
+    st["t"][:, :, 0, 0] += 250.0 * np.sqrt(2.0)
+    st["ps"] = (synth.spectra(2, sp.trunc, first=seed + 400) * 0.05).reshape(2, nx, mx)
+    st["phis"] = synth.spectra(1, sp.trunc, first=seed + 500)[0] * 2000.0
+    st["tcorh"] = synth.spectra(1, sp.trunc, first=seed + 600)[0] * 5.0
+    st["qcorh"] = synth.spectra(1, sp.trunc, first=seed + 700)[0] * 1e-3
+    return st
+
+
+@pytest.mark.parametrize("tag", ["t30", "t63", "t30k5", "t63k16"])
+def test_step_entry_points_vs_oracle(tag, oracle_factory):
+    import torch
+    sp, o = make_plan(tag, 64), oracle_factory(tag)
+    kx, nx, mx = sp.kx, sp.nx, sp.mx
+    sp.initialize_implicit(4800.0); o.tail_init(4800.0)
+    st = state(sp, 3000)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    vdt, ddt, tdt, qdt = (synth.cfield((kx, nx, mx), 60 + i, s) for i, s in enumerate((1e-9, 1e-10, 1e-4, 1e-7)))
+    psdt = synth.cfield((nx, mx), 70, 1e-7)
+    # --- get_spectral_tendencies (tendencies.f90:242-293), j2 = 2
+    d_div, d_t, d_ps, d_phis = dev(st["div"][1]), dev(st["t"][1]), dev(st["ps"][1]), dev(st["phis"])
+    g_ddt, g_tdt, g_psdt, g_phi = dev(ddt), dev(tdt), dev(psdt), torch.zeros((kx, nx, mx), dtype=torch.complex128, device="cuda")
+    sp.spectral_tendencies_dev(d_div, d_t, d_ps, d_phis, g_ddt, g_tdt, g_psdt, g_phi)
+    r_ddt, r_tdt, r_psdt, r_phi = o.spectral_tendencies(st["div"][1], st["t"][1], st["ps"][1], st["phis"], ddt, tdt, psdt)
+    torch.cuda.synchronize()
+    ok(g_ddt.cpu().numpy(), r_ddt); ok(g_tdt.cpu().numpy(), r_tdt); ok(g_psdt.cpu().numpy(), r_psdt); ok(g_phi.cpu().numpy(), r_phi)
+    assert g_psdt[0, 0].item() == 0
+    # --- get_geopotential on device
+    g_phi2 = torch.zeros_like(g_phi)
+    sp.geopotential_dev(d_t, d_phis, g_phi2)
+    torch.cuda.synchronize()
+    ok(g_phi2.cpu().numpy(), o.geopotential(st["t"][1], st["phis"]))
+    # --- the diffusion block of step() (time_stepping.f90:62-96), with and without the tracer
+    ins = [dev(st[n][0]) for n in ("vor", "div", "t", "tr")] + [dev(st["tcorh"]), dev(st["qcorh"])]
+    outs = [dev(x) for x in (vdt, ddt, tdt, qdt)]
+    sp.hdiff_step_dev(*ins, SDRAG, *outs)
+    ref = o.hdiff_step(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], st["tcorh"], st["qcorh"], SDRAG, vdt, ddt, tdt, qdt)
+    torch.cuda.synchronize()
+    for a, b in zip(outs, ref):
+        ok(a.cpu().numpy(), b)
+    outs2 = [dev(x) for x in (vdt, ddt, tdt)]
+    sp.hdiff_step_dev(ins[0], ins[1], ins[2], None, ins[4], None, SDRAG, *outs2, None)
+    torch.cuda.synchronize()
+    for a, b in zip(outs2, ref[:3]):
+        ok(a.cpu().numpy(), b)
+    # --- step_field_2d/3d (time_stepping.f90:121-167): forward step (j1 = 1, eps = 0) and filtered leapfrog (j1 = 2)
+    for j1, eps, dt in ((1, 0.0, 1200.0), (2, ROB, 4800.0)):
+        f3, f2 = dev(st["t"]), dev(st["ps"])
+        d3, d2 = dev(tdt), dev(psdt)
+        sp.step_fields_dev([(f2, d2), (f3, d3)], j1, dt, eps, WIL)
+        torch.cuda.synchronize()
+        r3, rd3 = o.step_field(j1, dt, eps, WIL, st["t"], tdt)
+        r2, rd2 = o.step_field(j1, dt, eps, WIL, st["ps"], psdt)
+        ok(f3.cpu().numpy(), r3); ok(f2.cpu().numpy(), r2); ok(d3.cpu().numpy(), rd3); ok(d2.cpu().numpy(), rd2)
+        # host-pointer form
+        h3, hd3 = sp.step_field(j1, dt, eps, WIL, st["t"], tdt)
+        ok(h3, r3); ok(hd3, rd3)
+    sp.close()
+
+
+def oracle_step(o, st, G, j1, dt, eps):
+    """One spectral-side step on the host, call by call (the reference's own sequence; the grid-space dynamics and
+    physics between the two transform batches are replaced by the given grid fields G)."""
+    kx = o.kx
+    j2 = 1                                                # leapfrog: dynamical tendencies from time level 2 (0-based 1)
+    out = {}
+    # inverse batch (tendencies.f90:89-101): uvspec + spec_to_grid(.,2) per level, spec_to_grid(.,1) of vor, div, t, tr
+    ug, vg = [], []
+    for k in range(kx):
+        u, v = o.uvspec(st["vor"][j2, k], st["div"][j2, k])
+        ug.append(o.spec_to_grid(u, 2)); vg.append(o.spec_to_grid(v, 2))
+    out["ug"], out["vg"] = np.stack(ug), np.stack(vg)
+    out["plain"] = np.stack([o.spec_to_grid(st[n][j2, k], 1) for n in ("vor", "div", "t", "tr") for k in range(kx)])
+    # direct batch (tendencies.f90:212-234 shape): 3 kx vdspec pairs + 3 kx + 1 plain fields
+    P = 3 * kx
+    vd = [o.vdspec(G["ug"][i], G["vg"][i], 2) for i in range(P)]
+    out["pvor"], out["pdiv"] = np.stack([x[0] for x in vd]), np.stack([x[1] for x in vd])
+    out["pspec"] = np.stack([o.grid_to_spec(G["plain"][i]) for i in range(P + 1)])
+    vordt, divdt = out["pvor"][:kx].copy(), out["pdiv"][:kx].copy()
+    tdt, trdt = out["pdiv"][kx:2 * kx].copy(), out["pdiv"][2 * kx:3 * kx].copy()
+    psdt = out["pspec"][P].copy()
+    # spectral tendencies + implicit correction (tendencies.f90:34-38)
+    divdt, tdt, psdt, phi = o.spectral_tendencies(st["div"][0], st["t"][0], st["ps"][0], st["phis"], divdt, tdt, psdt)
+    divdt, tdt, psdt = o.implicit_terms(divdt, tdt, psdt)
+    # diffusion + time integration (time_stepping.f90:62-118)
+    vordt, divdt, tdt, trdt = o.hdiff_step(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], st["tcorh"], st["qcorh"], SDRAG,
+                                           vordt, divdt, tdt, trdt)
+    new = dict(st)
+    new["ps"], _ = o.step_field(j1, dt, eps, WIL, st["ps"], psdt)
+    for n, d in (("vor", vordt), ("div", divdt), ("t", tdt), ("tr", trdt)):
+        new[n], _ = o.step_field(j1, dt, eps, WIL, st[n], d)
+    out["phi"] = phi
+    return new, out
+
+
+@pytest.mark.parametrize("tag", ["t30", "t63", "t63k16"])
+def test_model_step_graph(tag, oracle_factory):
+    """The whole spectral side of a time step -- both transform batches (spdy_inverse_batch_dev, spdy_direct_batch_dev),
+    get_spectral_tendencies, implicit_terms, the diffusion block and the leapfrog/RAW update of all five prognostics --
+    captured into ONE graph on device-resident state, replayed for two consecutive steps and compared with the oracle
+    call by call.  t63k16 is BASELINE.json config 5 (T63 L16)."""
+    import torch
+    kx = VARIANTS[tag][3]
+    sp, o = make_plan(tag, 4 * kx + 4), oracle_factory(tag)
+    nx, mx, il, ix = sp.nx, sp.mx, sp.il, sp.ix
+    dt = 4800.0
+    sp.initialize_implicit(dt); o.tail_init(dt)
+    st = state(sp, 5000)
+    P = 3 * kx
+    G = {"ug": synth.grids(P, ix, il, first=9000) * 1e-3, "vg": synth.grids(P, ix, il, first=9500) * 1e-3,
+         "plain": synth.grids(P + 1, ix, il, first=9900) * 1e-4}
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    D = {n: dev(st[n]) for n in st}
+    DG = {n: dev(G[n]) for n in G}
+    c128 = lambda *shape: torch.zeros(shape, dtype=torch.complex128, device="cuda")
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device="cuda")
+    ug, vg, plain_g = f64(kx, il, ix), f64(kx, il, ix), f64(4 * kx, il, ix)
+    pvor, pdiv, pspec = c128(P, nx, mx), c128(P, nx, mx), c128(P + 1, nx, mx)
+    phi = c128(kx, nx, mx)
+    torch.cuda.synchronize()
+    sp.use_own_stream()
+
+    # inverse batch from time level 2: kx (vor, div) pairs -> (u, v) grids; the vor, div, t, tr levels -> grids.  The plain
+    # fields of one launch are one contiguous stack, so they are gathered from the four prognostic arrays first
+    spec_plain = torch.cat([D[n][1] for n in ("vor", "div", "t", "tr")])          # [4 kx, nx, mx]
+    torch.cuda.synchronize()
+    with sp.graph_capture() as g:
+        sp.inverse_batch_dev(D["vor"][1], D["div"][1], ug, vg, spec_plain, plain_g, kcos_pairs=2, kcos=1)
+        sp.direct_batch_dev(DG["ug"], DG["vg"], pvor, pdiv, DG["plain"], pspec, kcos=2)
+        # tendencies are views into the direct batch's outputs: vordt/divdt = pair block 0, tdt = div of block 1, trdt = div of block 2
+        vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:3 * kx], pspec[P]
+        sp.spectral_tendencies_dev(D["div"][0], D["t"][0], D["ps"][0], D["phis"], divdt, tdt, psdt, phi)
+        sp.implicit_terms_dev(divdt, tdt, psdt)
+        sp.hdiff_step_dev(D["vor"][0], D["div"][0], D["t"][0], D["tr"][0], D["tcorh"], D["qcorh"], SDRAG, vordt, divdt, tdt, trdt)
+        sp.step_fields_dev([(D["ps"], psdt), (D["vor"], vordt), (D["div"], divdt), (D["t"], tdt), (D["tr"], trdt)], 2, dt, ROB, WIL)
+    assert float(ug.abs().max()) == 0.0                                           # nothing ran during the capture
+    ref = st
+    for step in range(2):
+        # the graph reads the plain spectra from spec_plain: refresh it from the (device-resident) prognostics
+        spec_plain.copy_(torch.cat([D[n][1] for n in ("vor", "div", "t", "tr")]))
+        torch.cuda.synchronize()
+        g.launch()
+        sp.synchronize()
+        ref, out = oracle_step(o, ref, G, 2, dt, ROB)
+        ok(ug.cpu().numpy(), out["ug"]); ok(vg.cpu().numpy(), out["vg"]); ok(plain_g.cpu().numpy(), out["plain"])
+        ok(phi.cpu().numpy(), out["phi"])
+        for n in ("ps", "vor", "div", "t", "tr"):
+            ok(D[n].cpu().numpy(), ref[n])
+    g.close()
+    sp.close()
