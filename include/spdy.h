@@ -229,6 +229,17 @@ int spdy_direct_batch_dev(spdy_plan *plan, int npairs, const double *d_ug, const
 int spdy_uvspec_to_grid(spdy_plan *plan, int nb, const double *vor, const double *div, double *ug, double *vg, int kcos);
 int spdy_grad_to_grid(spdy_plan *plan, int nb, const double *psi, double *gx, double *gy, int kcos);
 
+/* ---- output path: one snapshot's fields to the grid, scaled and rounded to float32 ------------------------------
+ * input_output.f90:184-206: per level uvspec + spec_to_grid(.,2) of (vor, div), spec_to_grid(.,1) of t, q (= tr(:,:,:,1,1)),
+ * phi, and of ps; then u, v, t unchanged, q*1.0e-3, phi/grav, p0*exp(ps), each converted with real(., sp).  The inputs are
+ * time level 1 of the device-resident prognostics ((mx,nx,kx) complex; ps (mx,nx)); the outputs are float arrays
+ * (ix,il,kx) / (ix,il) ready for the host's NetCDF writer (which stays on the host).  Three launches: gather of the plain
+ * spectra, ONE transform launch for all 5 kx + 1 fields, float32 epilogue.  spdy_output_workspace allocates the plan's
+ * scratch (5 kx + 1 grids) ahead of time, e.g. before a graph capture; max_batch must be >= 3 kx + 1.                    */
+int spdy_output_workspace(spdy_plan *plan);
+int spdy_output_batch_dev(spdy_plan *plan, const double *vor, const double *div, const double *t, const double *q, const double *phi,
+                          const double *ps, float *u_out, float *v_out, float *t_out, float *q_out, float *phi_out, float *ps_out);
+
 /* ---- HIP graphs: replaying a fixed sequence of device-resident calls --------------------------------
  * A model step is the same sequence of small launches every time (tendencies.f90:89-107, :212-234,
  * time_stepping.f90:56-121: ~90 inverse and ~70 direct transforms plus the spectral operators, 7 horizontal

@@ -180,6 +180,13 @@ class Oracle(_Dims):
                                 ctypes.c_double(wil), _ptr(f), _ptr(d))
         return f, d
 
+    def output(self, vor, div, t, q, phi, ps):
+        """input_output.f90:184-206 -> float32 (u, v, t, q, phi [kx,il,ix], ps [il,ix])."""
+        ins = [_c128(x) for x in (vor, div, t, q, phi, ps)]
+        outs = [np.empty((self.kx,) + self.grid_shape, np.float32) for _ in range(5)] + [np.empty(self.grid_shape, np.float32)]
+        self.lib.orc_output(self.ctx, *[_ptr(x) for x in ins], *[_ptr(x) for x in outs])
+        return outs
+
     def roundtrip_loop(self, g_in, nrep=1):
         g_in = _f64(g_in); out = np.empty_like(g_in)
         self.lib.orc_roundtrip_loop(self.ctx, ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))

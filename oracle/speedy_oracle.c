@@ -1082,6 +1082,32 @@ ORC_API void orc_step_field(const orc_ctx *c, int nlev, int j1, double dt, doubl
     free(fnew);
 }
 
+/* ------------------------------------------------------------------ input_output.f90:184-206: the gridded snapshot
+ * PARITY UNPINNED as a sequence (input_output.f90 needs the netcdf module); every transform/operator in it is pinned.
+ * Inputs: time level 1 of vor, div, t, q = tr(:,:,:,1,1), and phi, all (mx,nx,kx); ps (mx,nx).
+ * Outputs: float32 arrays u, v, t, q, phi (ix,il,kx) and ps (ix,il).                                              */
+ORC_API void orc_output(const orc_ctx *c, const double *vor, const double *div, const double *t, const double *q,
+                        const double *phi, const double *ps, float *u_out, float *v_out, float *t_out, float *q_out,
+                        float *phi_out, float *ps_out)
+{
+    const int kx = c->kx, ns = 2 * c->mx * c->nx, ng = c->ix * c->il;
+    double *ucos = dalloc((size_t)ns), *vcos = dalloc((size_t)ns), *g = dalloc((size_t)ng);
+    int k, i;
+    for (k = 0; k < kx; ++k) {
+        orc_uvspec(c, vor + (size_t)ns * k, div + (size_t)ns * k, ucos, vcos);                     /* :185 */
+        orc_spec_to_grid(c, ucos, 2, g); for (i = 0; i < ng; ++i) u_out[(size_t)ng * k + i] = (float)g[i];          /* :186, :201 */
+        orc_spec_to_grid(c, vcos, 2, g); for (i = 0; i < ng; ++i) v_out[(size_t)ng * k + i] = (float)g[i];          /* :187, :202 */
+        orc_spec_to_grid(c, t + (size_t)ns * k, 1, g); for (i = 0; i < ng; ++i) t_out[(size_t)ng * k + i] = (float)g[i];   /* :188, :203 */
+        orc_spec_to_grid(c, q + (size_t)ns * k, 1, g);                                              /* :189, :204 q*1.0e-3 [f32 literal] */
+        for (i = 0; i < ng; ++i) q_out[(size_t)ng * k + i] = (float)(g[i] * (double)1.0e-3f);
+        orc_spec_to_grid(c, phi + (size_t)ns * k, 1, g);                                            /* :190, :205 phi/grav */
+        for (i = 0; i < ng; ++i) phi_out[(size_t)ng * k + i] = (float)(g[i] / GRAV);
+    }
+    orc_spec_to_grid(c, ps, 1, g);                                                                  /* :192, :206 p0*exp(ps) */
+    for (i = 0; i < ng; ++i) ps_out[i] = (float)(P0 * exp(g[i]));
+    free(ucos); free(vcos); free(g);
+}
+
 /* ------------------------------------------------------------------ context */
 ORC_API orc_ctx *orc_create(int trunc, int ix, int iy, int kx)
 {

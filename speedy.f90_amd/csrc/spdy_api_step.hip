@@ -216,6 +216,53 @@ int spdy_step_field(spdy_plan *p, int nlev, int j1, double dt, double eps, doubl
 }
 
 
+/* ---------------------------------------------------------------- output path */
+int spdy_output_workspace(spdy_plan *p)
+{
+    NEED_DEVICE(p);
+    if (p->out_grid) return SPDY_OK;
+    NOT_CAPTURING(p, "allocating the output workspace (call spdy_output_workspace before the capture)");
+    const int kx = p->tab.kx;
+    void *ptr;
+    RC(dev_alloc(p, (size_t)(5 * kx + 1) * grid_elems(p) * sizeof(double), &ptr));
+    p->out_grid = static_cast<double *>(ptr);
+    RC(dev_alloc(p, (size_t)(3 * kx + 1) * spec_elems(p) * sizeof(double), &ptr));
+    p->out_spec = static_cast<double *>(ptr);
+    return SPDY_OK;
+}
+
+int spdy_output_batch_dev(spdy_plan *p, const double *vor, const double *div, const double *t, const double *q, const double *phi,
+                          const double *ps, float *u_out, float *v_out, float *t_out, float *q_out, float *phi_out, float *ps_out)
+{
+    NEED_DEVICE(p);
+    if (!vor || !div || !t || !q || !phi || !ps || !u_out || !v_out || !t_out || !q_out || !phi_out || !ps_out)
+        return fail(SPDY_ERR_ARG, "null device pointer");
+    const int kx = p->tab.kx;
+    if (p->max_batch < 3 * kx + 1) return fail(SPDY_ERR_ARG, "max_batch must be >= 3*kx+1 for the output batch");
+    RC(spdy_output_workspace(p));
+    const size_t gs = grid_elems(p), ss = spec_elems(p);
+    // t, q, phi levels and ps into one stack: the whole snapshot is then one transform launch
+    spdy::GatherOps g{};
+    g.nops = 4;
+    const double *src[4] = {t, q, phi, ps};
+    for (int i = 0; i < 4; ++i) { g.nfld[i] = i < 3 ? kx : 1; g.src[i] = src[i]; g.dst[i] = p->out_spec + (size_t)i * kx * ss; }
+    KERNEL(spdy::launch_gather_spectra(p->dev, g, p->stream));
+    double *ug = p->out_grid, *vg = ug + (size_t)kx * gs, *plain = vg + (size_t)kx * gs;
+    RC(spdy_inverse_batch_dev(p, kx, vor, div, ug, vg, 2, 3 * kx + 1, p->out_spec, nullptr, 1, plain));
+    // input_output.f90:200-206: u, v, t as they are; q*1.0e-3; phi/grav; p0*exp(ps) -- then real(., sp)
+    spdy::OutputCast c{};
+    c.nops = 6;
+    float *dst[6] = {u_out, v_out, t_out, q_out, phi_out, ps_out};
+    const int kind[6] = {0, 0, 0, 1, 2, 3};
+    const double fac[6] = {1.0, 1.0, 1.0, static_cast<double>(1.0e-3f), p->tab.grav, static_cast<double>(1.e+5f)};
+    for (int i = 0; i < 6; ++i) {
+        c.nfld[i] = i < 5 ? kx : 1; c.kind[i] = kind[i]; c.factor[i] = fac[i];
+        c.src[i] = p->out_grid + (size_t)i * kx * gs; c.dst[i] = dst[i];
+    }
+    KERNEL(spdy::launch_output_cast(p->dev, c, p->stream));
+    return SPDY_OK;
+}
+
 /* ---------------------------------------------------------------- level all-gather over RCCL (xGMI) */
 }  // extern "C"
 

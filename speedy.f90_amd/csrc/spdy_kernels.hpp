@@ -109,6 +109,11 @@ hipError_t launch_geopotential(const DevPlan &p, const double *t, const double *
 // get_spectral_tendencies (tendencies.f90:242-293); phi is written as the reference's module variable is
 hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const double *t, const double *ps, const double *phis,
                                       double *divdt, double *tdt, double *psdt, double *phi, hipStream_t s);
+// output path (input_output.f90:184-206)
+struct GatherOps { int nops, nfld[8]; const double *src[8]; double *dst[8]; };
+hipError_t launch_gather_spectra(const DevPlan &p, const GatherOps &g, hipStream_t s);
+struct OutputCast { int nops, nfld[8], kind[8]; double factor[8]; const double *src[8]; float *dst[8]; };
+hipError_t launch_output_cast(const DevPlan &p, const OutputCast &c, hipStream_t s);
 // once per device, before the first launch: raises the dynamic-LDS limit of every kernel that needs > 64 KB
 hipError_t prepare_device_kernels();
 hipError_t prepare_device_step_kernels(int kx);

@@ -28,6 +28,7 @@ struct spdy_plan {
     double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;
     size_t stage_elems = 0;
     double *tmp_c = nullptr, *tmp_d = nullptr;   // max_batch spectra each; allocated with `four` (multi-kernel operator sequences)
+    double *out_grid = nullptr, *out_spec = nullptr;   // output path: (5kx+1) grids, (3kx+1) spectra (spdy_output_workspace)
     int *d_kcos = nullptr;
     // device copies of dt-dependent tables
     double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

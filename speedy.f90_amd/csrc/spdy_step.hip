@@ -248,4 +248,55 @@ hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Output path (input_output.f90:184-206): after the 5 kx + 1 inverse transforms, the gridded fields are scaled and
+// rounded to float32.  gather_spectra packs the separately stored plain spectra (t, q, phi levels and ps) into one
+// stack so that the whole snapshot is ONE transform launch; output_cast does the float32 epilogue.
+// ------------------------------------------------------------------------------------------
+__global__ void gather_spectra_kernel(GatherOps g, int sz2)
+{
+    const int op = blockIdx.y;
+    const long total = (long)g.nfld[op] * sz2, i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // in double2 units
+    if (i >= total) return;
+    reinterpret_cast<double2 *>(g.dst[op])[i] = reinterpret_cast<const double2 *>(g.src[op])[i];
+}
+
+hipError_t launch_gather_spectra(const DevPlan &p, const GatherOps &g, hipStream_t s)
+{
+    int maxf = 0;
+    for (int i = 0; i < g.nops; ++i) maxf = std::max(maxf, g.nfld[i]);
+    const int sz2 = p.mx * p.nx;                                    // complex = one double2
+    const long total = (long)maxf * sz2;
+    if (g.nops <= 0 || total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_spectra_kernel, dim3((unsigned)((total + 255) / 256), g.nops), dim3(256), 0, s, g, sz2);
+    return hipGetLastError();
+}
+
+// kind per segment: 0 plain, 1 times `factor`, 2 divided by `factor`, 3 factor*exp(x)
+__global__ void output_cast_kernel(OutputCast c, int gsz)
+{
+    const int op = blockIdx.y;
+    const long total = (long)c.nfld[op] * gsz, i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= total) return;
+    const double2 v = *reinterpret_cast<const double2 *>(c.src[op] + i);
+    const int kind = c.kind[op];
+    const double f = c.factor[op];
+    double a = v.x, b = v.y;
+    if (kind == 1) { a = a * f; b = b * f; }
+    else if (kind == 2) { a = a / f; b = b / f; }
+    else if (kind == 3) { a = f * exp(a); b = f * exp(b); }
+    *reinterpret_cast<float2 *>(c.dst[op] + i) = make_float2((float)a, (float)b);
+}
+
+hipError_t launch_output_cast(const DevPlan &p, const OutputCast &c, hipStream_t s)
+{
+    int maxf = 0;
+    for (int i = 0; i < c.nops; ++i) maxf = std::max(maxf, c.nfld[i]);
+    const int gsz = p.ix * p.il;                                    // even
+    const long pairs = (long)maxf * gsz / 2;
+    if (c.nops <= 0 || pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(output_cast_kernel, dim3((unsigned)((pairs + 255) / 256), c.nops), dim3(256), 0, s, c, gsz);
+    return hipGetLastError();
+}
+
 }  // namespace spdy

@@ -365,6 +365,12 @@ class Spectral:
         self._sync_stream()
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
 
+    def output_batch_dev(self, vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out):
+        """input_output.f90:184-206 on device-resident state: complex128 [kx,nx,mx] (ps [nx,mx]) in, float32 [kx,il,ix]
+        (ps_out [il,ix]) out."""
+        args = (vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out)
+        check(self.lib.spdy_output_batch_dev(self.h, *[self._dp(x) for x in args]))
+
     def geopotential_dev(self, t, phis, phi):
         self._sync_stream()
         check(self.lib.spdy_geopotential_dev(self.h, self._dp(t), self._dp(phis), self._dp(phi)))

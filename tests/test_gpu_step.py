@@ -189,3 +189,40 @@ def test_model_step_graph(tag, oracle_factory):
             ok(D[n].cpu().numpy(), ref[n])
     g.close()
     sp.close()
+
+
+@pytest.mark.parametrize("tag", ["t30", "t63"])
+def test_output_path(tag, oracle_factory):
+    """the snapshot path of input_output.f90:184-206 as one device call.  float32 results must be
+    BIT-EXACT where the epilogue is linear (u, v, t, q*1e-3, phi/grav: an inverse-transform difference of 1e-15 only
+    shows when a value sits within that distance of a float32 rounding boundary -- counted, at most a handful); ps_out
+    goes through exp(), so it is held to one float32 ulp."""
+    import torch
+    sp, o = make_plan(tag, 4 * 8 + 4), oracle_factory(tag)
+    kx, nx, mx, il, ix = sp.kx, sp.nx, sp.mx, sp.il, sp.ix
+    st = state(sp, 7000)
+    phi = o.geopotential(st["t"][0], st["phis"])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ins = [dev(st[n][0]) for n in ("vor", "div", "t", "tr")] + [dev(phi), dev(st["ps"][0])]
+    outs = [torch.zeros((kx, il, ix), dtype=torch.float32, device="cuda") for _ in range(5)] + [torch.zeros((il, ix), dtype=torch.float32, device="cuda")]
+    sp.output_batch_dev(*ins, *outs)
+    torch.cuda.synchronize()
+    ref = o.output(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], phi, st["ps"][0])
+    flips = 0
+    for name, a, b in zip(("u", "v", "t", "q", "phi", "ps"), outs, ref):
+        a = a.cpu().numpy()
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, (name, ulp.max())
+        flips += int((ulp != 0).sum())
+        assert synth.relerr(a.astype(np.float64), b.astype(np.float64)) <= 2e-7
+    assert flips <= 8, flips          # of ~190k (T30) / ~750k (T63) float32 values
+    # captured into a graph it gives the same bits
+    sp.use_own_stream()
+    outs2 = [torch.zeros_like(x) for x in outs]
+    torch.cuda.synchronize()
+    with sp.graph_capture() as g:
+        sp.output_batch_dev(*ins, *outs2)
+    g.launch(); sp.synchronize()
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    g.close(); sp.close()
