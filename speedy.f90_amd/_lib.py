@@ -8,7 +8,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspdy.so")
+LIB_PATH = os.environ.get("SPDY_LIB") or os.path.join(HERE, "libspdy.so")   # SPDY_LIB: an alternative build (experiments)
 
 c_void_p, c_int, c_double, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "spdy_plan.hpp"
+#include "spdy_t63_sched.hpp"
 
 using spdy::DevPlan;
 using spdy::HostTables;
@@ -114,6 +115,42 @@ void build_packed_tables(const HostTables &t, int ks_inv, int js_dir, std::vecto
     }
 }
 
+// A-operand images of the fused T63 kernels (spdy_fused_t63.inc): per Legendre wave and slot (quad q, parity, n-group g)
+// one double2 per lane and latitude chunk; 4x4x4 block = zonal wavenumber 4q+blk, A row = lane&3, k = lane>>4.
+//   direct : A[i = n row][k = lat]  = P(m,n,lat)*wt(lat),  .x/.y = the chunk's two k-steps of 4 latitudes
+//   inverse: A[i = lat][k = n]      = P(m,n,lat),          .x/.y = the chunk's two groups of 4 latitudes
+void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector<double> &inv)
+{
+    using namespace spdy::t63;
+    const int mx = t.mx, nx = t.nx;
+    auto P = [&](int m, int n, int j) { return t.poly[m + mx * (n + (size_t)nx * j)]; };
+    dir.assign((size_t)NLW * MAXS * NCH * 64 * 2, 0.0);
+    inv.assign((size_t)NLW * MAXS * NCH * 64 * 2, 0.0);
+    for (int w = 0; w < NLW; ++w)
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave_quad(w, i);
+            for (int par = 0; par < 2; ++par)
+                for (int dirflag = 0; dirflag < 2; ++dirflag)
+                    for (int g = 0; g < ngrp(dirflag, q, par); ++g) {
+                        const int s = slot_of(dirflag, w, i, par, g);
+                        for (int c = 0; c < NCH; ++c)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int h = 0; h < 2; ++h) {
+                                    const int blk = (lane >> 2) & 3, row = lane & 3, k = lane >> 4, m = 4 * q + blk;
+                                    double v = 0.0;
+                                    if (dirflag) {
+                                        const int n = 2 * (4 * g + row) + par, lat = CP * c + 4 * h + k;
+                                        if (n <= t.trunc && m + n <= t.trunc + 1) v = P(m, n, lat) * t.wt[lat];
+                                    } else {
+                                        const int n = 2 * (4 * g + k) + par, lat = CP * c + 4 * h + row;
+                                        if (n < nx && m + n <= t.trunc + 1) v = P(m, n, lat);
+                                    }
+                                    (dirflag ? dir : inv)[((((size_t)w * MAXS + s) * NCH + c) * 64 + lane) * 2 + h] = v;
+                                }
+                    }
+        }
+}
+
 int upload_all(spdy_plan *p)
 {
     HostTables &t = p->tab;
@@ -165,6 +202,12 @@ int upload_all(spdy_plan *p)
                 }
             }
         UP(is2g, img_s2g); UP(ig2s, img_g2s);
+    }
+    d.img_g2s63 = d.img_s2g63 = nullptr;
+    if (t.trunc == 63) {
+        std::vector<double> i63d, i63i;
+        build_t63_images(t, i63d, i63i);
+        UP(i63d, img_g2s63); UP(i63i, img_s2g63);
     }
     UP(t.el2, el2); UP(t.elm2, elm2); UP(t.trfilt, trfilt); UP(t.gradx, gradx); UP(t.gradym, gradym);
     UP(t.gradyp, gradyp); UP(t.uvdx, uvdx); UP(t.uvdym, uvdym); UP(t.uvdyp, uvdyp); UP(t.vddym, vddym);
@@ -322,6 +365,9 @@ bool use_fused(const spdy_plan *p, int nb)
     (void)nb;
     return p->tab.trunc == 30 && p->fused_mode != 0;
 }
+// T63: fused field-pair kernels for the plain transforms (spdy_fused_t63.inc); the operator-fused modes use the
+// multi-kernel sequences
+bool use_fused63(const spdy_plan *p) { return p->tab.trunc == 63 && p->fused_mode != 0 && getenv("SPDY_NO_FUSED63") == nullptr; }
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
@@ -525,6 +571,8 @@ int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_
         return timed(p, SPDY_K_G2S_FUSED, [&] {
             return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu * p->wg_per_cu, p->stream);
         });
+    if (use_fused63(p))
+        return timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu, p->stream); });
     RC(ensure_four(p));
     RC(timed(p, SPDY_K_FOURIER_DIR, [&] { return spdy::launch_fourier_dir(p->dev, nb, d_grid, nullptr, p->four, p->stream); }));
     RC(timed(p, SPDY_K_LEGENDRE_DIR, [&] { return spdy::launch_legendre_dir(p->dev, nb, p->four, d_spec, p->stream); }));

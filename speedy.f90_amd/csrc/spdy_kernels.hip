@@ -14,6 +14,7 @@
 // Legendre sums differ -> agreement ~1e-15 relative, bar 1e-12.
 #include "spdy_kernels.hpp"
 #include "spdy_cpx.hpp"
+#include "spdy_t63_sched.hpp"
 
 namespace spdy {
 
@@ -23,6 +24,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // FFT constants (uniform -> scalar loads).  96 and 192 share the ido=12 / ido=3 stage twiddles
 // mathematically, but each resolution keeps its own copy so plans of both can coexist.
 // ------------------------------------------------------------------------------------------
+#ifdef SPDY_PAD
+__device__ __attribute__((used)) char g_layout_pad[SPDY_PAD];   // code-object layout experiments
+#endif
 __constant__ FftConstants c_fft96;
 __constant__ FftConstants c_fft192;
 
@@ -797,6 +801,7 @@ __global__ void hdiff_kernel(int sz, long total, const double *__restrict__ fiel
 }
 
 #include "spdy_fused_t30.inc"
+#include "spdy_fused_t63.inc"
 
 // ------------------------------------------------------------------------------------------
 // Launchers
@@ -816,6 +821,7 @@ hipError_t prepare_device_kernels()
         {reinterpret_cast<const void *>(s2g_fused_t30_kernel<2>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<3>), t30::S2G_LDS},
         {reinterpret_cast<const void *>(g2s_fused_t30_kernel<0>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<1>), t30::G2S_LDS},
         {reinterpret_cast<const void *>(g2s_fused_t30_kernel<2>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<3>), t30::G2S_LDS},
+        {reinterpret_cast<const void *>(g2s_fused_t63_kernel<0>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(g2s_fused_t63_kernel<1>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {
         hipError_t e = hipFuncSetAttribute(b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.bytes);

@@ -21,6 +21,8 @@ struct DevPlan {
     // the same fragments in the order the fused T30 kernels keep them in registers, two per 16-byte load:
     const double *img_s2g;  // [4 Legendre waves][30][64 lanes][2]
     const double *img_g2s;  // [4 Legendre waves][36][64 lanes][2]
+    // A-operand images of the fused T63 kernels: [4 Legendre waves][38 slots][6 chunks][64 lanes][2] (spdy_t63_sched.hpp)
+    const double *img_g2s63, *img_s2g63;
     const double *cosgr;    // [il]
     const double *cosgr2;   // [il]
     // spectral operator tables, each [nx][mx] (gradx: [mx])
@@ -71,6 +73,9 @@ hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const 
 hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg,
                             hipStream_t s, const double *grid2 = nullptr, double *spec2 = nullptr, int nplain = 0,
                             const double *grid_p = nullptr, double *spec_p = nullptr);
+
+// Fused T63 kernels: a pair of fields per tile, six latitude chunks, accumulators / B operands resident in VGPRs
+hipError_t launch_g2s_fused_t63(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg, hipStream_t s);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };
 hipError_t launch_scale_op(const DevPlan &p, int op, int nb, const double *in, double *out, hipStream_t s);

@@ -1,0 +1,36 @@
+// Compile-time work schedule of the fused T63 kernels, shared by the kernels (spdy_fused_t63.inc) and the host code
+// that builds their MFMA A-operand images (spdy_api.hip).  Plain constexpr C++: usable on both sides.
+#pragma once
+namespace spdy {
+namespace t63 {
+constexpr int TRUNC = 63, MX = 64, NX = 65, IY = 48, IL = 96, IX = 192;
+constexpr int CP = 8, NCH = IY / CP;                         // latitude pairs per chunk, chunks per field pair
+constexpr int CROWS = 4 * CP;                                // LDS rows of a chunk: [field 2][half 2: lat, IL-1-lat][CP]
+constexpr int RS = IX + 1, BUF = CROWS * RS;                 // row stride (odd), doubles per chunk buffer
+constexpr int NLW = 4, NFW = 4, NTHR = 64 * (NLW + NFW);     // Legendre waves, FFT waves (two groups of two), 512 threads
+constexpr int NBUF = 3;                                      // chunk buffers: FFT group A, FFT group B, Legendre
+constexpr int NQ = MX / 4;                                   // 16 quads of zonal wavenumbers
+constexpr int SPEC_C = MX * NX;
+constexpr int TW = 144;                                      // ido = 48 radix-4 twiddles
+constexpr int LDS_BYTES = (NBUF * BUF + TW) * 8 + 4 * 68;     // 149,648 B (+ the zero-fill row table)
+constexpr int MAXS = 38;                                     // slots per Legendre wave (both directions)
+
+// DIR = true: direct transform writes n <= trunc with m'+n <= trunc+1 (legendre.f90:142-154);
+// DIR = false: inverse transform reads m'+n <= trunc+1, n up to nx-1 (legendre.f90:92-103)
+constexpr int nmax(bool dir, int q) { return dir ? (TRUNC < TRUNC + 1 - 4 * q ? TRUNC : TRUNC + 1 - 4 * q) : TRUNC + 1 - 4 * q; }
+constexpr int ncount(bool dir, int q, int par) { return par == 0 ? nmax(dir, q) / 2 + 1 : (nmax(dir, q) + 1) / 2; }
+constexpr int ngrp(bool dir, int q, int par) { return (ncount(dir, q, par) + 3) / 4; }
+constexpr int wave_quad(int w, int i) { return i == 0 ? w : i == 1 ? 15 - w : i == 2 ? 4 + w : 11 - w; }
+// slot index of (quad position i, parity, n-group g) within wave w
+constexpr int slot_of(bool dir, int w, int i, int par, int g)
+{
+    int s = 0;
+    for (int ii = 0; ii < i; ++ii) s += ngrp(dir, wave_quad(w, ii), 0) + ngrp(dir, wave_quad(w, ii), 1);
+    if (par) s += ngrp(dir, wave_quad(w, i), 0);
+    return s + g;
+}
+constexpr int nslots(bool dir, int w) { return slot_of(dir, w, 4, 0, 0); }
+static_assert(nslots(true, 0) <= MAXS && nslots(true, 1) <= MAXS && nslots(true, 2) <= MAXS && nslots(true, 3) <= MAXS, "direct slots");
+static_assert(nslots(false, 0) <= MAXS && nslots(false, 1) <= MAXS && nslots(false, 2) <= MAXS && nslots(false, 3) <= MAXS, "inverse slots");
+}  // namespace t63
+}  // namespace spdy

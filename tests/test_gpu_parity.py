@@ -37,7 +37,7 @@ def ok(x, ref, tol=TOL):
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("tag,fused", [("t30", 0), ("t30", 1), ("t63", 0)])
+@pytest.mark.parametrize("tag,fused", [("t30", 0), ("t30", 1), ("t63", 0), ("t63", 1)])
 def test_stages_vs_golden(tag, fused, plans, golden):
     g, sp = golden(tag), plans(tag, fused=fused)
     nb = g["leginv"].shape[0]
@@ -63,7 +63,7 @@ def test_stages_vs_golden(tag, fused, plans, golden):
     assert np.all(sp.fourier_dir(G)[:, :, 1] == 0)      # Im(m'=0) written as 0 (fourier.f90:76)
 
 
-@pytest.mark.parametrize("tag,fused", [("t30", 0), ("t30", 1), ("t63", 0)])
+@pytest.mark.parametrize("tag,fused", [("t30", 0), ("t30", 1), ("t63", 0), ("t63", 1)])
 def test_operators_vs_golden(tag, fused, plans, golden):
     g, sp = golden(tag), plans(tag, fused=fused)
     S, G = g["S"], g["G"]
@@ -96,7 +96,8 @@ def test_tail_vs_golden(tag, plans, golden):
 @pytest.mark.parametrize("tag,nb,fused", [("t30", 1, 0), ("t30", 7, 0), ("t30", 48, 0), ("t30", 73, 0), ("t30", 91, 0),
                                           ("t30", 129, 0), ("t30", 1, 1), ("t30", 2, 1), ("t30", 5, 1), ("t30", 48, 1),
                                           ("t30", 73, 1), ("t30", 91, 1), ("t30", 129, 1), ("t30", 255, 1),
-                                          ("t63", 1, 0), ("t63", 9, 0), ("t63", 96, 0)])
+                                          ("t63", 1, 0), ("t63", 9, 0), ("t63", 96, 0),
+                                          ("t63", 1, 1), ("t63", 2, 1), ("t63", 9, 1), ("t63", 96, 1), ("t63", 255, 1)])
 def test_batches_vs_oracle(tag, nb, fused, plans, oracle_factory):
     """Model-shaped batches (48 / 73 / 91) and ragged ones (partial 4-field tiles of the
     fused kernels), mixed kcos, through both kernel paths."""
@@ -145,7 +146,7 @@ def test_max_batch_enforced(plans):
         sp.grid_to_spec(np.zeros((257,) + sp.grid_shape))
 
 
-@pytest.mark.parametrize("tag,nb,fused", [("t30", 6144, 1), ("t30", 6143, 1), ("t30", 6144, 0), ("t63", 1536, 0)])
+@pytest.mark.parametrize("tag,nb,fused", [("t30", 6144, 1), ("t30", 6143, 1), ("t30", 6144, 0), ("t63", 1536, 0), ("t63", 1536, 1), ("t63", 1535, 1)])
 def test_full_size_device_resident(tag, nb, fused, oracle_factory):
     """BASELINE sizes (B=6144 at T30, 1536 at T63; ~226 MB of grid data), device-resident path on
     torch's stream.  Checked against the oracle on a strided sample of fields plus two
