@@ -821,6 +821,7 @@ hipError_t prepare_device_kernels()
         {reinterpret_cast<const void *>(s2g_fused_t30_kernel<2>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<3>), t30::S2G_LDS},
         {reinterpret_cast<const void *>(g2s_fused_t30_kernel<0>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<1>), t30::G2S_LDS},
         {reinterpret_cast<const void *>(g2s_fused_t30_kernel<2>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<3>), t30::G2S_LDS},
+        {reinterpret_cast<const void *>(s2g_fused_t63_kernel), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(g2s_fused_t63_kernel<0>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(g2s_fused_t63_kernel<1>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {

@@ -75,6 +75,8 @@ hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const 
                             const double *grid_p = nullptr, double *spec_p = nullptr);
 
 // Fused T63 kernels: a pair of fields per tile, six latitude chunks, accumulators / B operands resident in VGPRs
+hipError_t launch_s2g_fused_t63(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid, int max_wg,
+                                hipStream_t s);
 hipError_t launch_g2s_fused_t63(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg, hipStream_t s);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };
