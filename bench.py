@@ -43,12 +43,45 @@ def algorithmic_bytes(sp):
             "round_trip": 2 * (spec + grid)}
 
 
-def cpu_baseline(res, sample_fields=256, target_s=10.0):
-    """Reference CPU path on one host core, bounded to ~target_s seconds."""
+def host_topology():
+    """Logical CPUs of socket 0, one per physical core (for the 'single socket' baseline of the north star), + a description."""
+    cpus = {}
+    base = "/sys/devices/system/cpu"
+    try:
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                t = os.path.join(base, d, "topology")
+                pkg = int(open(os.path.join(t, "physical_package_id")).read())
+                core = int(open(os.path.join(t, "core_id")).read())
+                cpus.setdefault(pkg, {}).setdefault(core, []).append(int(d[3:]))
+    except Exception:
+        pass
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    allowed = os.sched_getaffinity(0)
+    if not cpus:
+        return sorted(allowed), {"model": model, "sockets": None, "cores_per_socket": None, "logical_cpus": os.cpu_count()}
+    pkg0 = min(cpus)
+    one_per_core = [min(v) for v in cpus[pkg0].values() if min(v) in allowed] or sorted(allowed)
+    return sorted(one_per_core), {"model": model, "sockets": len(cpus), "cores_per_socket": len(cpus[pkg0]),
+                                  "logical_cpus": os.cpu_count()}
+
+
+def cpu_baseline(res, variant="", sample_fields=256, target_s=8.0):
+    """Reference CPU path on one host core, bounded to ~target_s seconds.  variant "" = the flang -O2 build the parity
+    oracle is defined by; "fast" = -O3 -ffast-math -march=x86-64-v3 (upstream builds -Ofast, gfortran.makefile:18)."""
     import synth
     from oracle.pyoracle import Oracle, Reference, RESOLUTIONS
-    if Reference.available(res):
-        impl, kind = Reference(res), "reference"
+    if Reference.available(res + variant):
+        impl, kind = Reference(res + variant), "reference"
+    elif variant:
+        return None
     else:
         impl, kind = Oracle(*RESOLUTIONS[res]), "port"
     G = synth.grids(sample_fields, impl.ix, impl.il, first=0)
@@ -60,34 +93,109 @@ def cpu_baseline(res, sample_fields=256, target_s=10.0):
     impl.roundtrip_loop(G, nrep)
     dt = time.perf_counter() - t0
     return {"value": sample_fields * nrep / dt, "unit": "round trips/s", "cores": 1, "kind": kind,
+            "build": "flang -O3 -ffast-math -march=x86-64-v3" if variant else "flang -O2",
             "sample": "%d passes over %d synthetic %s fields (grid_to_spec + spec_to_grid, one field at a "
-                      "time), %.1f s on one core of %d" % (nrep, sample_fields, res.upper(), dt, os.cpu_count() or 1)}
+                      "time), %.1f s on one core" % (nrep, sample_fields, res.upper(), dt)}
 
 
-def cpu_baseline_all_cores(res, fields=64, target_s=4.0):
-    """The same reference loop on every host core at once: one PROCESS per core (oracle/cpu_worker.py), each
-    transforming its own fields one at a time for ~target_s seconds.  The reference itself is single-threaded;
-    this is the generous 'whole host' number next to the single-core one."""
+def cpu_baseline_socket(res, variant="fast", fields=64, target_s=4.0):
+    """The same single-threaded reference loop on every physical core of ONE socket at once: one pinned PROCESS per core
+    (oracle/cpu_worker.py), each transforming its own fields one at a time for ~target_s seconds.  This is the
+    'single-socket CPU baseline' of the north star, with the faster (fast-math) build of the reference."""
     import subprocess
-    nproc = os.cpu_count() or 1
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), res, str(fields), str(target_s)]
+    cpus, topo = host_topology()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(nproc)]
-    total, rate, kind, ok = 0, 0.0, "reference", 0
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), res, str(fields), str(target_s),
+                               variant, str(c)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for c in cpus]
+    rate, kind, ok = 0.0, "reference", 0
     for pr in procs:
         try:
             out, _ = pr.communicate(timeout=60 + 10 * target_s)
             n, dt, kind = out.split()
-            total += int(n)
             rate += int(n) / float(dt)
             ok += 1
         except Exception:
             pr.kill()
     wall = time.perf_counter() - t0
     return {"value": rate, "unit": "round trips/s", "cores": ok, "kind": kind,
-            "sample": "%d processes (one per logical core), each %.0f s over its own %d synthetic %s fields; sum of the "
-                      "per-process rates; %.1f s wall incl. start-up" % (ok, target_s, fields, res.upper(), wall)}
+            "build": "flang -O3 -ffast-math -march=x86-64-v3" if variant else "flang -O2", "host": topo,
+            "sample": "%d pinned processes (one per physical core of socket 0), each %.0f s over its own %d synthetic %s "
+                      "fields; sum of the per-process rates; %.1f s wall incl. start-up" % (ok, target_s, fields, res.upper(), wall)}
+
+
+def _time_us(torch, sp, fn, reps=20, warm=3):
+    """Average duration of fn() in microseconds (HIP events on the plan's stream via torch events on the same stream)."""
+    for _ in range(warm):
+        fn()
+    sp.synchronize()
+    sp.use_torch_stream()                       # events and kernels on one stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    sp.use_own_stream()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def extras(s, torch, synth, sp, dev, args):
+    """Side measurements the N=1 line carries outside `value`: the kernels a real model step uses
+    (operator-fused and mixed-batch modes, model-shaped batch sizes) and the other resolution."""
+    out = {}
+    gb = lambda nbytes, us: nbytes / (us * 1e-6) / 1e9
+    if sp.trunc == 30:
+        grid_b, spec_b = sp.ix * sp.il * 8, sp.mx * sp.nx * 16
+        c128 = lambda n: torch.zeros((n, sp.nx, sp.mx), dtype=torch.complex128, device=dev)
+        f64 = lambda n: torch.randn((n, sp.il, sp.ix), dtype=torch.float64, device=dev)
+        # one-pass vdspec, 3072 (u, v) pairs (spectral.f90:198-227; 6 of every 9 direct transforms of a step)
+        npair = 3072
+        ug, vg, vor, div = f64(npair), f64(npair), c128(npair), c128(npair)
+        us = _time_us(torch, sp, lambda: sp.vdspec_dev(ug, vg, vor, div, 2))
+        byt = npair * 2 * (grid_b + spec_b)
+        out["vdspec_one_pass"] = {"pairs": npair, "us": us, "GB/s": gb(byt, us), "frac_of_8TBs": gb(byt, us) / HBM_PEAK_GBS}
+        # uvspec -> two grids in one pass (tendencies.f90:98-100)
+        us = _time_us(torch, sp, lambda: sp.uvspec_to_grid_dev(vor, div, ug, vg, 2))
+        out["uvspec_to_grid"] = {"pairs": npair, "us": us, "GB/s": gb(byt, us), "frac_of_8TBs": gb(byt, us) / HBM_PEAK_GBS}
+        # a step's whole inverse / direct batch in one launch each, throughput size (2048 pairs + 2048 plain fields)
+        pl_s, pl_g = c128(2048), f64(2048)
+        us = _time_us(torch, sp, lambda: sp.inverse_batch_dev(vor[:2048], div[:2048], ug[:2048], vg[:2048], pl_s, pl_g))
+        byt = 6144 * (grid_b + spec_b)
+        out["inverse_batch_6144"] = {"fields": 6144, "us": us, "GB/s": gb(byt, us), "frac_of_8TBs": gb(byt, us) / HBM_PEAK_GBS}
+        us = _time_us(torch, sp, lambda: sp.direct_batch_dev(ug[:2048], vg[:2048], vor[:2048], div[:2048], pl_g, pl_s))
+        out["direct_batch_6144"] = {"fields": 6144, "us": us, "GB/s": gb(byt, us), "frac_of_8TBs": gb(byt, us) / HBM_PEAK_GBS}
+        # model-shaped batches of the T30 L8 step (SURVEY s3.4): 91 inverse (8 uvspec pairs + 75 plain), 73 direct
+        # (24 vdspec pairs + 25 plain), 48 (8 pairs + 32 plain) -- latency-bound: microseconds per launch
+        for name, (np_, npl) in (("inverse_91", (8, 75)), ("inverse_48", (8, 32))):
+            us = _time_us(torch, sp, lambda: sp.inverse_batch_dev(vor[:np_], div[:np_], ug[:np_], vg[:np_], pl_s[:npl], pl_g[:npl]), reps=50)
+            out[name] = {"fields": 2 * np_ + npl, "us_per_launch": us, "fields_per_s": (2 * np_ + npl) / (us * 1e-6)}
+        us = _time_us(torch, sp, lambda: sp.direct_batch_dev(ug[:24], vg[:24], vor[:24], div[:24], pl_g[:25], pl_s[:25]), reps=50)
+        out["direct_73"] = {"fields": 73, "us_per_launch": us, "fields_per_s": 73 / (us * 1e-6)}
+        del ug, vg, vor, div, pl_s, pl_g
+    # the other BASELINE resolution, same definition of a round trip (config 4: T63, B = 1536)
+    other = "t63" if sp.trunc == 30 else "t30"
+    nb2 = 1536 if other == "t63" else 6144
+    sp2 = s.Spectral(other, kx=8, max_batch=nb2, device=dev.index or 0)
+    sp2.use_own_stream()
+    g2 = torch.randn((nb2, sp2.il, sp2.ix), dtype=torch.float64, device=dev)
+    s2 = torch.zeros((nb2, sp2.nx, sp2.mx), dtype=torch.complex128, device=dev)
+    o2 = torch.zeros_like(g2)
+    torch.cuda.synchronize()
+
+    def rt():
+        sp2.grid_to_spec_dev(g2, s2)
+        sp2.spec_to_grid_dev(s2, o2, kcos=1)
+    us = _time_us(torch, sp2, rt, reps=30, warm=10)
+    sp2.set_profiling(True)
+    for _ in range(10):
+        rt()
+    prof = {k: ms / max(c, 1) * 1e3 for k, (ms, c) in sp2.get_profile().items() if c}
+    byt = 2 * nb2 * (sp2.ix * sp2.il * 8 + sp2.mx * sp2.nx * 16)
+    out[other + "_round_trip"] = {"fields": nb2, "round_trips_per_s": nb2 / (us * 1e-6), "us_per_step": us, "kernel_us": prof,
+                                  "path_hbm_frac": gb(byt, us) / HBM_PEAK_GBS}
+    sp2.close()
+    return out
 
 
 def main():
@@ -98,6 +206,7 @@ def main():
     ap.add_argument("--res", default="t30", choices=["t30", "t63"])
     ap.add_argument("--batch", type=int, default=0, help="fields per GPU (default 6144 at T30, 1536 at T63)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the model-shaped / operator-fused / T63 side measurements")
     ap.add_argument("--fused", type=int, default=-1, help="1 fused single-pass kernels, 0 four-kernel path, -1 auto")
     args = ap.parse_args()
 
@@ -145,18 +254,26 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = s.sharding.max_over_ranks(max(wall, e0.elapsed_time(e1) / 1e3), dev)
+    # The timed region is EXACTLY args.steps steps between barrier + synchronize on both sides.  When that region is short
+    # (< 30 ms: the default 200 steps are 30 ms, the driver's --steps 20 only 3 ms) it is repeated up to 3 times and the best
+    # block is reported -- a 3 ms window right after start-up mostly measures the clock ramp.
+    blocks = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        blocks.append(s.sharding.max_over_ranks(max(wall, e0.elapsed_time(e1) / 1e3), dev))
+        if blocks[-1] >= 0.030:
+            break
+    elapsed = min(blocks)
 
     # per-kernel launch durations: HIP events on the launch stream, outside the timed region
     sp.set_profiling(True)
@@ -170,7 +287,23 @@ def main():
     # all-gather of the implicit solve's inputs over RCCL -- timed on its own so the scaling of the
     # transform metric can be read "with and without the gather"
     gather_ms = None
+    gather_cabi_ms = None
     if dist and args.res == "t30":
+        try:   # the same exchange through the C ABI (spdy_comm_*: one grouped RCCL call on the plan's stream)
+            comm = s.sharding.LevelComm(sp)
+            full = [torch.zeros((sp.kx, sp.nx, sp.mx), dtype=torch.complex128, device=dev) for _ in range(2)]
+            for _ in range(5):
+                comm.allgather_levels_(*full)
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                comm.allgather_levels_(*full)
+            torch.cuda.synchronize()
+            gather_cabi_ms = s.sharding.max_over_ranks((time.perf_counter() - t0) / 50 * 1e3, dev)
+            comm.close()
+        except Exception as e:
+            if rank == 0:
+                print("C-ABI all-gather timing skipped: %s" % e, file=sys.stderr)
         try:
             lo, hi = s.sharding.shard_range(sp.kx, rank, world)
             loc = torch.zeros((hi - lo, sp.nx, sp.mx), dtype=torch.complex128, device=dev)
@@ -205,7 +338,7 @@ def main():
         res = {
             "metric": "spectral transforms/sec (grid<->spec round-trip) at %s L8" % args.res.upper(),
             "value": value, "unit": "round trips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "timed_blocks_s": blocks, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (%dx%d grid, trunc %d) device-resident batch of %d 2-D fields per GPU "
                                    "(field x level index sharded over ranks, no collective); one step = "
@@ -221,11 +354,20 @@ def main():
         }
         if world > 1:
             res["implicit_allgather_ms"] = gather_ms   # 2 x all-gather of [kx, nx, mx] complex level slabs, per model step
+            res["implicit_allgather_cabi_ms"] = gather_cabi_ms   # the same as ONE grouped RCCL call (spdy_allgather_levels_dev)
+        if world == 1 and not args.no_extras:
+            try:
+                res["extras"] = extras(s, torch, synth, sp, dev, args)
+            except Exception as e:   # the extras never break the headline line
+                res["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.res)
+            res["cpu_baseline"] = cpu_baseline(args.res)                     # the parity oracle's build (flang -O2), one core
             res["gpu_over_cpu_core"] = value / res["cpu_baseline"]["value"]
-            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.res)
-            res["gpu_over_cpu_all_cores"] = value / res["cpu_baseline_all_cores"]["value"]
+            fast = cpu_baseline(args.res, "fast")                            # upstream-like -Ofast build, one core
+            if fast:
+                res["cpu_baseline_fast_math"] = fast
+            res["cpu_baseline_socket"] = cpu_baseline_socket(args.res, "fast" if fast else "")
+            res["gpu_over_cpu_socket"] = value / res["cpu_baseline_socket"]["value"]
         print(json.dumps(res))
     sp.close()
     if dist:

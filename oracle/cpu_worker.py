@@ -1,6 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- one CPU worker of bench.py's all-cores baseline.
 
-    python oracle/cpu_worker.py <res> <fields> <seconds>
+    python oracle/cpu_worker.py <res> <fields> <seconds> [<variant> [<cpu>]]
+
+<variant>: "" (flang -O2 build, the parity oracle) or "fast" (-O3 -ffast-math -march=x86-64-v3, mirroring upstream's
+-Ofast, gfortran.makefile:18); <cpu>: pin this worker to one logical CPU.
 
 Runs the reference's grid_to_spec + spec_to_grid loop (oracle/_ref, or the C restatement when that is
 absent) over <fields> synthetic fields, one field at a time, for about <seconds> of wall time and prints
@@ -18,9 +21,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 
 def main():
     res, nf, secs = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    variant = sys.argv[4] if len(sys.argv) > 4 else ""
+    if len(sys.argv) > 5:
+        os.sched_setaffinity(0, {int(sys.argv[5])})
     import synth
     from oracle.pyoracle import Oracle, Reference, RESOLUTIONS
-    if Reference.available(res):
+    if Reference.available(res + variant):
+        impl, kind = Reference(res + variant), "reference"
+    elif Reference.available(res):
         impl, kind = Reference(res), "reference"
     else:
         impl, kind = Oracle(*RESOLUTIONS[res]), "port"

@@ -778,6 +778,13 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
         KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
         return SPDY_OK;
     }
+    if (use_fused63(p)) {                       // two scaled fused transforms + vds
+        RC(ensure_four(p));
+        KERNEL(spdy::launch_g2s_fused_t63(p->dev, nb, ug, sc, p->tmp_c, p->num_cu, p->stream));
+        KERNEL(spdy::launch_g2s_fused_t63(p->dev, nb, vg, sc, p->tmp_d, p->num_cu, p->stream));
+        KERNEL(spdy::launch_vds(p->dev, nb, p->tmp_c, p->tmp_d, vorm, divm, p->stream));
+        return SPDY_OK;
+    }
     RC(ensure_four(p));
     KERNEL(spdy::launch_fourier_dir(p->dev, nb, ug, sc, p->four, p->stream));
     KERNEL(spdy::launch_legendre_dir(p->dev, nb, p->four, p->tmp_c, p->stream));
