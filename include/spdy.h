@@ -186,6 +186,23 @@ typedef struct {
 int spdy_step_fields_dev(spdy_plan *plan, int nops, const spdy_step_op *ops, int j1, double dt, double eps, double wil);
 int spdy_step_field(spdy_plan *plan, int nlev, int j1, double dt, double eps, double wil, double *field, double *fdt);
 
+/* ---- grid-space dynamical tendencies (tendencies.f90:105-197) --------------------------------------
+ * Closes the loop inverse batch -> nonlinear terms -> direct batch on the device: from the gridded prognostics of time
+ * level j2 (ug, vg, tg, vorg, divg, trg: (ix,il,kx) each, exactly what spdy_inverse_batch_dev produced -- vorg without
+ * the Coriolis term, it is added here) and px, py = spec_to_grid(grad(ps), 2) it computes the vertical means, the
+ * sigma-dot velocities and every grid tendency, laid out as the operands of ONE spdy_direct_batch_dev launch:
+ *     u_out, v_out [3 kx] : (utend, vtend) | (-ug*tgg, -vg*tgg) | (-ug*trg, -vg*trg)
+ *     plain_out [3 kx+1]  : 0.5*(ug^2+vg^2) | ttend | trtend | -umean*px - vmean*py
+ * A host with physics adds its tendencies to utend, vtend, ttend, trtend in place before the direct batch
+ * (tendencies.f90:203-206).  After the direct batch (pvor, pdiv [3 kx] from the pairs, pspec [3 kx + 1] from the plain
+ * fields) spdy_tendency_combine_dev finishes tendencies.f90:125-126, 218-233 in place: pdiv[0:kx] -= laplacian(pspec[0:kx]),
+ * pdiv[kx:3kx] += pspec[kx:3kx], pspec[3kx](1,1) = 0 -- so vordt = pvor[0:kx], divdt = pdiv[0:kx], tdt = pdiv[kx:2kx],
+ * trdt = pdiv[2kx:3kx], psdt = pspec[3kx] are views, no copies.                                                     */
+int spdy_grid_tendencies_dev(spdy_plan *plan, const double *ug, const double *vg, const double *tg, const double *vorg,
+                             const double *divg, const double *trg, const double *px, const double *py, double *u_out,
+                             double *v_out, double *plain_out);
+int spdy_tendency_combine_dev(spdy_plan *plan, double *pdiv, double *pspec);
+
 /* ---- multi-GPU: the one exchange a level-sharded step needs (one process per GPU, RCCL over xGMI) ------------
  * The transform batch shards over (field x level) with no communication.  implicit_terms couples all levels of a
  * coefficient (implicit.f90:174-216), so ranks that own level blocks complete each other's divdt/tdt first.

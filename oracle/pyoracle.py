@@ -180,6 +180,18 @@ class Oracle(_Dims):
                                 ctypes.c_double(wil), _ptr(f), _ptr(d))
         return f, d
 
+    def grid_tendencies(self, ug, vg, tg, vorg, divg, trg, px, py):
+        """tendencies.f90:105-197 -> (u [3kx,il,ix], v [3kx,il,ix], plain [3kx+1,il,ix]) in the direct batch's layout."""
+        ins = [_f64(x) for x in (ug, vg, tg, vorg, divg, trg, px, py)]
+        kx = self.kx
+        u = np.zeros((3 * kx,) + self.grid_shape); v = np.zeros_like(u); pl = np.zeros((3 * kx + 1,) + self.grid_shape)
+        self.lib.orc_grid_tendencies(self.ctx, *[_ptr(x) for x in ins], _ptr(u), _ptr(v), _ptr(pl))
+        return u, v, pl
+
+    def tendency_combine(self, pdiv, pspec):
+        a = _c128(pdiv).copy(); b = _c128(pspec).copy()
+        self.lib.orc_tendency_combine(self.ctx, _ptr(a), _ptr(b)); return a, b
+
     def output(self, vor, div, t, q, phi, ps):
         """input_output.f90:184-206 -> float32 (u, v, t, q, phi [kx,il,ix], ps [il,ix])."""
         ins = [_c128(x) for x in (vor, div, t, q, phi, ps)]

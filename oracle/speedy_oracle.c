@@ -1108,6 +1108,90 @@ ORC_API void orc_output(const orc_ctx *c, const double *vor, const double *div, 
     free(ucos); free(vcos); free(g);
 }
 
+/* ------------------------------------------------------------------ tendencies.f90:105-197: grid-space dynamical tendencies
+ * PARITY UNPINNED (tendencies.f90 needs the netcdf chain).  Inputs: gridded prognostics of time level j2 (vorg WITHOUT
+ * Coriolis: added here as :103-107 does), px, py = spec_to_grid(grad(ps), 2).  Outputs in the layout of the direct batch:
+ * u, v [3 kx] = (utend, vtend) | (-ug*tgg, -vg*tgg) | (-ug*trg, -vg*trg); plain [3 kx + 1] = KE | ttend | trtend | psdt grid. */
+ORC_API void orc_grid_tendencies(const orc_ctx *c, const double *ug, const double *vg, const double *tg, const double *vorg_in,
+                                 const double *divg, const double *trg, const double *px, const double *py,
+                                 double *u, double *v, double *plain)
+{
+    const int kx = c->kx, g = c->ix * c->il, ix = c->ix;
+    const double rgas = akap_() * CP, akap = akap_();
+    double *vorg = dalloc((size_t)g * kx), *umean = dalloc(g), *vmean = dalloc(g), *dmean = dalloc(g);
+    double *puv = dalloc((size_t)g * kx), *tgg = dalloc((size_t)g * kx);
+    double *sigdt = dalloc((size_t)g * (kx + 1)), *sigm = dalloc((size_t)g * (kx + 1)), *temp = dalloc((size_t)g * (kx + 1));
+    double *utend = u, *vtend = v, *ttend = plain + (size_t)g * kx, *trtend = plain + (size_t)2 * g * kx;
+    int k, i;
+#define A3(a, k_) ((a) + (size_t)g * (k_))
+    for (k = 0; k < kx; ++k)
+        for (i = 0; i < g; ++i) A3(vorg, k)[i] = A3(vorg_in, k)[i] + c->coriol[i / ix];                 /* :103-107 */
+    for (k = 0; k < kx; ++k)                                                                             /* :113-117 */
+        for (i = 0; i < g; ++i) {
+            umean[i] = umean[i] + A3(ug, k)[i] * c->dhs[k];
+            vmean[i] = vmean[i] + A3(vg, k)[i] * c->dhs[k];
+            dmean[i] = dmean[i] + A3(divg, k)[i] * c->dhs[k];
+        }
+    for (i = 0; i < g; ++i) A3(plain, 3 * kx)[i] = -umean[i] * px[i] - vmean[i] * py[i];                /* :125 */
+    for (k = 0; k < kx; ++k)                                                                             /* :135-137 */
+        for (i = 0; i < g; ++i) A3(puv, k)[i] = (A3(ug, k)[i] - umean[i]) * px[i] + (A3(vg, k)[i] - vmean[i]) * py[i];
+    for (k = 0; k < kx; ++k)                                                                             /* :139-142 */
+        for (i = 0; i < g; ++i) {
+            A3(sigdt, k + 1)[i] = A3(sigdt, k)[i] - c->dhs[k] * (A3(puv, k)[i] + A3(divg, k)[i] - dmean[i]);
+            A3(sigm, k + 1)[i] = A3(sigm, k)[i] - c->dhs[k] * A3(puv, k)[i];
+        }
+    for (k = 0; k < kx; ++k)                                                                             /* :146-148 */
+        for (i = 0; i < g; ++i) A3(tgg, k)[i] = A3(tg, k)[i] - c->tref[k];
+    for (k = 1; k < kx; ++k)                                                                             /* :155-157 (temp(1) = temp(kx+1) = 0) */
+        for (i = 0; i < g; ++i) A3(temp, k)[i] = A3(sigdt, k)[i] * (A3(ug, k)[i] - A3(ug, k - 1)[i]);
+    for (k = 0; k < kx; ++k)                                                                             /* :159-162 */
+        for (i = 0; i < g; ++i)
+            A3(utend, k)[i] = A3(vg, k)[i] * A3(vorg, k)[i] - A3(tgg, k)[i] * rgas * px[i] - (A3(temp, k + 1)[i] + A3(temp, k)[i]) * c->dhsr[k];
+    for (k = 1; k < kx; ++k)                                                                             /* :165-167 */
+        for (i = 0; i < g; ++i) A3(temp, k)[i] = A3(sigdt, k)[i] * (A3(vg, k)[i] - A3(vg, k - 1)[i]);
+    for (k = 0; k < kx; ++k)                                                                             /* :169-172 */
+        for (i = 0; i < g; ++i)
+            A3(vtend, k)[i] = -A3(ug, k)[i] * A3(vorg, k)[i] - A3(tgg, k)[i] * rgas * py[i] - (A3(temp, k + 1)[i] + A3(temp, k)[i]) * c->dhsr[k];
+    for (k = 1; k < kx; ++k)                                                                             /* :175-178 */
+        for (i = 0; i < g; ++i)
+            A3(temp, k)[i] = A3(sigdt, k)[i] * (A3(tgg, k)[i] - A3(tgg, k - 1)[i]) + A3(sigm, k)[i] * (c->tref[k] - c->tref[k - 1]);
+    for (k = 0; k < kx; ++k)                                                                             /* :180-184 */
+        for (i = 0; i < g; ++i)
+            A3(ttend, k)[i] = A3(tgg, k)[i] * A3(divg, k)[i] - (A3(temp, k + 1)[i] + A3(temp, k)[i]) * c->dhsr[k]
+                              + c->fsgr[k] * A3(tgg, k)[i] * (A3(sigdt, k + 1)[i] + A3(sigdt, k)[i])
+                              + c->tref3[k] * (A3(sigm, k + 1)[i] + A3(sigm, k)[i])
+                              + akap * (A3(tg, k)[i] * A3(puv, k)[i] - A3(tgg, k)[i] * dmean[i]);
+    for (k = 1; k < kx; ++k)                                                                             /* :187-189 */
+        for (i = 0; i < g; ++i) A3(temp, k)[i] = A3(sigdt, k)[i] * (A3(trg, k)[i] - A3(trg, k - 1)[i]);
+    for (k = 1; k <= 2 && k <= kx; ++k)                                                                  /* :191 temp(:,:,2:3) = 0 */
+        for (i = 0; i < g; ++i) A3(temp, k)[i] = 0.0;
+    for (k = 0; k < kx; ++k)                                                                             /* :193-195 */
+        for (i = 0; i < g; ++i)
+            A3(trtend, k)[i] = A3(trg, k)[i] * A3(divg, k)[i] - (A3(temp, k + 1)[i] + A3(temp, k)[i]) * c->dhsr[k];
+    for (k = 0; k < kx; ++k)                                                                             /* operands of :216-232 */
+        for (i = 0; i < g; ++i) {
+            A3(plain, k)[i] = 0.5 * (A3(ug, k)[i] * A3(ug, k)[i] + A3(vg, k)[i] * A3(vg, k)[i]);
+            A3(u, kx + k)[i] = -A3(ug, k)[i] * A3(tgg, k)[i];      A3(v, kx + k)[i] = -A3(vg, k)[i] * A3(tgg, k)[i];
+            A3(u, 2 * kx + k)[i] = -A3(ug, k)[i] * A3(trg, k)[i];  A3(v, 2 * kx + k)[i] = -A3(vg, k)[i] * A3(trg, k)[i];
+        }
+#undef A3
+    free(vorg); free(umean); free(vmean); free(dmean); free(puv); free(tgg); free(sigdt); free(sigm); free(temp);
+}
+
+/* tendencies.f90:125-126, 218-233 in spectral space, on the outputs of the direct batch (see spdy_tendency_combine_dev) */
+ORC_API void orc_tendency_combine(const orc_ctx *c, double *pdiv, double *pspec)
+{
+    const int kx = c->kx, sz = c->mx * c->nx;
+    int k, i;
+    for (k = 0; k < kx; ++k)
+        for (i = 0; i < sz; ++i) {
+            cset(pdiv, k * sz + i, csub(cget(pdiv, k * sz + i), rmul(c->el2[i], cneg(cget(pspec, k * sz + i)))));
+            cset(pdiv, (kx + k) * sz + i, cadd(cget(pdiv, (kx + k) * sz + i), cget(pspec, (kx + k) * sz + i)));
+            cset(pdiv, (2 * kx + k) * sz + i, cadd(cget(pdiv, (2 * kx + k) * sz + i), cget(pspec, (2 * kx + k) * sz + i)));
+        }
+    pspec[2 * (size_t)3 * kx * sz] = 0.0; pspec[2 * (size_t)3 * kx * sz + 1] = 0.0;
+}
+
 /* ------------------------------------------------------------------ context */
 ORC_API orc_ctx *orc_create(int trunc, int ix, int iy, int kx)
 {

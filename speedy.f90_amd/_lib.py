@@ -73,6 +73,8 @@ SIGNATURES = {
     "spdy_comm_level_range": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "spdy_allgather_levels_dev": [c_void_p, c_int, c_int, c_void_p],
     "spdy_implicit_terms_sharded_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_grid_tendencies_dev": [c_void_p] * 12,
+    "spdy_tendency_combine_dev": [c_void_p, c_void_p, c_void_p],
     "spdy_output_workspace": [c_void_p],
     "spdy_output_batch_dev": [c_void_p] * 13,
     "spdy_graph_begin": [c_void_p],

@@ -216,6 +216,26 @@ int spdy_step_field(spdy_plan *p, int nlev, int j1, double dt, double eps, doubl
 }
 
 
+/* ---------------------------------------------------------------- grid-space dynamical tendencies */
+int spdy_grid_tendencies_dev(spdy_plan *p, const double *ug, const double *vg, const double *tg, const double *vorg, const double *divg,
+                             const double *trg, const double *px, const double *py, double *u_out, double *v_out, double *plain_out)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "grid_tendencies needs the reference temperature profile: call spdy_implicit_init first");
+    if (!ug || !vg || !tg || !vorg || !divg || !trg || !px || !py || !u_out || !v_out || !plain_out) return fail(SPDY_ERR_ARG, "null device pointer");
+    const spdy::GridTend g{ug, vg, tg, vorg, divg, trg, px, py, u_out, v_out, plain_out};
+    KERNEL(spdy::launch_grid_tendencies(p->dev, g, p->stream));
+    return SPDY_OK;
+}
+
+int spdy_tendency_combine_dev(spdy_plan *p, double *pdiv, double *pspec)
+{
+    NEED_DEVICE(p);
+    if (!pdiv || !pspec) return fail(SPDY_ERR_ARG, "null device pointer");
+    KERNEL(spdy::launch_tendency_combine(p->dev, pdiv, pspec, p->stream));
+    return SPDY_OK;
+}
+
 /* ---------------------------------------------------------------- output path */
 int spdy_output_workspace(spdy_plan *p)
 {

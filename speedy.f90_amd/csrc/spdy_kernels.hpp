@@ -116,6 +116,14 @@ hipError_t launch_geopotential(const DevPlan &p, const double *t, const double *
 // get_spectral_tendencies (tendencies.f90:242-293); phi is written as the reference's module variable is
 hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const double *t, const double *ps, const double *phis,
                                       double *divdt, double *tdt, double *psdt, double *phi, hipStream_t s);
+// grid-space dynamical tendencies (tendencies.f90:105-197) and their spectral-space combination (:125-126, 218-233)
+struct GridTend {
+    const double *ug, *vg, *tg, *vorg, *divg, *trg;   // [kx] grids each (vorg WITHOUT the Coriolis term)
+    const double *px, *py;                            // grad(ps) on the grid
+    double *u, *v, *plain;                            // [3 kx], [3 kx], [3 kx + 1] grids: operands of the direct batch
+};
+hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
+hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec, hipStream_t s);
 // output path (input_output.f90:184-206)
 struct GatherOps { int nops, nfld[8]; const double *src[8]; double *dst[8]; };
 hipError_t launch_gather_spectra(const DevPlan &p, const GatherOps &g, hipStream_t s);

@@ -249,6 +249,100 @@ hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const
 }
 
 // ------------------------------------------------------------------------------------------
+// Grid-space dynamical tendencies (tendencies.f90:105-197): one lane per grid point, the level recurrences
+// (vertical means, sigma-dot, the half-level "temp" fluxes) stream through registers with a one-level look-ahead.
+// Inputs are the results of the step's inverse transforms; outputs are laid out as the operands of ONE
+// spdy_direct_batch_dev launch (tendencies.f90:212-234):
+//   U, V [3 kx]      : (utend, vtend) | (-ug*tgg, -vg*tgg) | (-ug*trg, -vg*trg)      -> three kx-stacks of vdspec pairs
+//   plain [3 kx + 1] : 0.5*(ug^2 + vg^2) | ttend | trtend | -umean*px - vmean*py
+// (the host adds its physical tendencies to utend, vtend, ttend, trtend in between, tendencies.f90:203-206).
+// ------------------------------------------------------------------------------------------
+__global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
+{
+    const int gsz = p.ix * p.il, kx = p.kx, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= gsz) return;
+    const int j = i / p.ix;
+    const double cor = p.coriol[j], px = g.px[i], py = g.py[i], rgas = p.rgas, akap = p.akap;
+#define LV(a, k) (a)[(long)(k) * gsz + i]
+    // vertical means (:109-117)
+    double umean = 0.0, vmean = 0.0, dmean = 0.0;
+    for (int k = 0; k < kx; ++k) {
+        const double dh = p.dhs[k];
+        umean = umean + LV(g.ug, k) * dh;
+        vmean = vmean + LV(g.vg, k) * dh;
+        dmean = dmean + LV(g.divg, k) * dh;
+    }
+    g.plain[(long)(3 * kx) * gsz + i] = (-umean) * px - vmean * py;                       // (:125)
+    // level sweep: at level k the fluxes temp(k), temp(k+1) of the three advected quantities are needed, i.e. sigdt(k),
+    // sigdt(k+1) and the fields of levels k-1, k, k+1
+    double sig = 0.0, sigm = 0.0;                                                          // sigdt(k), sigm(k): level 1 = 0
+    double ug_m = 0.0, vg_m = 0.0, tgg_m = 0.0, tr_m = 0.0;                                // fields of level k-1
+    double ug_c = LV(g.ug, 0), vg_c = LV(g.vg, 0), tg_c = LV(g.tg, 0), tr_c = LV(g.trg, 0);
+    double tu = 0.0, tv = 0.0, tt = 0.0, tq = 0.0;                                         // temp(k) of u, v, t, tracer (temp(1) = 0)
+    for (int k = 0; k < kx; ++k) {
+        const double dh = p.dhs[k], dhr = p.dhsr[k];
+        const double vor = LV(g.vorg, k) + cor, dv = LV(g.divg, k);                        // (:103-107 coriolis)
+        const double tgg = tg_c - p.tref[k];                                               // (:149)
+        const double puv = (ug_c - umean) * px + (vg_c - vmean) * py;                      // (:136)
+        const double sig1 = sig - dh * (puv + dv - dmean);                                 // sigdt(k+1) (:139-142; the loop also sets level kx+1)
+        const double sigm1 = sigm - dh * puv;
+        // next level's fields and fluxes temp(k+1) (zero at kx+1: :152-153)
+        double ug_n = 0.0, vg_n = 0.0, tg_n = 0.0, tr_n = 0.0, tu1 = 0.0, tv1 = 0.0, tt1 = 0.0, tq1 = 0.0;
+        if (k + 1 < kx) {
+            ug_n = LV(g.ug, k + 1); vg_n = LV(g.vg, k + 1); tg_n = LV(g.tg, k + 1); tr_n = LV(g.trg, k + 1);
+            const double tgg_n = tg_n - p.tref[k + 1];
+            tu1 = sig1 * (ug_n - ug_c);                                                    // (:156)
+            tv1 = sig1 * (vg_n - vg_c);                                                    // (:166)
+            tt1 = sig1 * (tgg_n - tgg) + sigm1 * (p.tref[k + 1] - p.tref[k]);              // (:176-177)
+            tq1 = sig1 * (tr_n - tr_c);                                                    // (:188)
+            if (k + 1 == 1 || k + 1 == 2) tq1 = 0.0;                                       // temp(:,:,2:3) = 0 (:191)
+        }
+        LV(g.u, k) = vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr;                      // utend (:160-161)
+        LV(g.v, k) = -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr;                     // vtend (:170-171)
+        LV(g.plain, kx + k) = tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
+                              + akap * (tg_c * puv - tgg * dmean);                         // ttend (:181-184)
+        LV(g.plain, 2 * kx + k) = tr_c * dv - (tq1 + tq) * dhr;                            // trtend (:194)
+        LV(g.plain, k) = 0.5 * (ug_c * ug_c + vg_c * vg_c);                                // kinetic energy (:220)
+        LV(g.u, kx + k) = -ug_c * tgg;  LV(g.v, kx + k) = -vg_c * tgg;                     // (:224)
+        LV(g.u, 2 * kx + k) = -ug_c * tr_c;  LV(g.v, 2 * kx + k) = -vg_c * tr_c;           // (:229)
+        sig = sig1; sigm = sigm1;
+        ug_m = ug_c; vg_m = vg_c; tgg_m = tgg; tr_m = tr_c;
+        ug_c = ug_n; vg_c = vg_n; tg_c = tg_n; tr_c = tr_n;
+        tu = tu1; tv = tv1; tt = tt1; tq = tq1;
+    }
+    (void)ug_m; (void)vg_m; (void)tgg_m; (void)tr_m;
+#undef LV
+}
+
+hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s)
+{
+    const int gsz = p.ix * p.il;
+    hipLaunchKernelGGL(grid_tendencies_kernel, dim3((gsz + 63) / 64), dim3(64), 0, s, p, g);
+    return hipGetLastError();
+}
+
+// The spectral-space end of get_grid_point_tendencies (tendencies.f90:125-126, 218-233), in place on the outputs of the
+// direct batch: divdt -= laplacian(KE) ; tdt += ttend ; trdt += trtend ; psdt(1,1) = 0.
+//   pdiv [3 kx] = (divdt | tdt part | trdt part) from the vdspec pairs, pspec [3 kx + 1] = (KE | ttend | trtend | psdt)
+__global__ void tendency_combine_kernel(DevPlan p, double *__restrict__ pdiv, double *__restrict__ pspec)
+{
+    const int sz = p.mx * p.nx, kx = p.kx;
+    const long total = (long)3 * kx * sz, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) st(pspec, (long)3 * kx * sz, cpx{0.0, 0.0});
+    if (i >= total) return;
+    const int e = (int)(i % sz), blk = (int)(i / ((long)kx * sz));
+    const cpx a = ld(pdiv, i), b = ld(pspec, i);
+    st(pdiv, i, blk == 0 ? a - p.el2[e] * (-b) : a + b);
+}
+
+hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec, hipStream_t s)
+{
+    const long total = (long)3 * p.kx * p.mx * p.nx;
+    hipLaunchKernelGGL(tendency_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, pdiv, pspec);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Output path (input_output.f90:184-206): after the 5 kx + 1 inverse transforms, the gridded fields are scaled and
 // rounded to float32.  gather_spectra packs the separately stored plain spectra (t, q, phi levels and ps) into one
 // stack so that the whole snapshot is ONE transform launch; output_cast does the float32 epilogue.

@@ -365,9 +365,21 @@ class Spectral:
         self._sync_stream()
         check(self.lib.spdy_implicit_terms_dev(self.h, self._dp(divdt), self._dp(tdt), self._dp(psdt)))
 
+    def grid_tendencies_dev(self, ug, vg, tg, vorg, divg, trg, px, py, u_out, v_out, plain_out):
+        """tendencies.f90:105-197 on the gridded prognostics; outputs are the operands of one direct_batch_dev launch."""
+        self._sync_stream()
+        args = (ug, vg, tg, vorg, divg, trg, px, py, u_out, v_out, plain_out)
+        check(self.lib.spdy_grid_tendencies_dev(self.h, *[self._dp(x) for x in args]))
+
+    def tendency_combine_dev(self, pdiv, pspec):
+        """In place on the direct batch's outputs: divdt -= laplacian(KE), tdt += ttend, trdt += trtend, psdt(1,1) = 0."""
+        self._sync_stream()
+        check(self.lib.spdy_tendency_combine_dev(self.h, self._dp(pdiv), self._dp(pspec)))
+
     def output_batch_dev(self, vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out):
         """input_output.f90:184-206 on device-resident state: complex128 [kx,nx,mx] (ps [nx,mx]) in, float32 [kx,il,ix]
         (ps_out [il,ix]) out."""
+        self._sync_stream()
         args = (vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out)
         check(self.lib.spdy_output_batch_dev(self.h, *[self._dp(x) for x in args]))
 

@@ -226,3 +226,86 @@ def test_output_path(tag, oracle_factory):
     for a, b in zip(outs, outs2):
         assert torch.equal(a, b)
     g.close(); sp.close()
+
+
+def oracle_dynamics_step(o, st, j1, dt, eps):
+    """One adiabatic time step of the dynamical core on the host, the reference's own call sequence (tendencies.f90:11-41,
+    time_stepping.f90:35-118 without get_physical_tendencies): inverse transforms of time level j2 = 2, grid-space
+    tendencies, direct transforms, spectral tendencies, implicit correction, diffusion, leapfrog/RAW."""
+    kx, j2 = o.kx, 1
+    ug, vg = [], []
+    for k in range(kx):
+        u, v = o.uvspec(st["vor"][j2, k], st["div"][j2, k])
+        ug.append(o.spec_to_grid(u, 2)); vg.append(o.spec_to_grid(v, 2))
+    ug, vg = np.stack(ug), np.stack(vg)
+    vorg, divg, tg, trg = (np.stack([o.spec_to_grid(st[n][j2, k], 1) for k in range(kx)]) for n in ("vor", "div", "t", "tr"))
+    dx, dy = o.grad(st["ps"][j2])
+    px, py = o.spec_to_grid(dx, 2), o.spec_to_grid(dy, 2)
+    U, V, PL = o.grid_tendencies(ug, vg, tg, vorg, divg, trg, px, py)
+    P = 3 * kx
+    vd = [o.vdspec(U[i], V[i], 2) for i in range(P)]
+    pvor, pdiv = np.stack([x[0] for x in vd]), np.stack([x[1] for x in vd])
+    pspec = np.stack([o.grid_to_spec(PL[i]) for i in range(P + 1)])
+    pdiv, pspec = o.tendency_combine(pdiv, pspec)
+    vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
+    divdt, tdt, psdt, phi = o.spectral_tendencies(st["div"][0], st["t"][0], st["ps"][0], st["phis"], divdt, tdt, psdt)
+    divdt, tdt, psdt = o.implicit_terms(divdt, tdt, psdt)
+    vordt, divdt, tdt, trdt = o.hdiff_step(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], st["tcorh"], st["qcorh"], SDRAG,
+                                           vordt, divdt, tdt, trdt)
+    new = dict(st)
+    new["ps"], _ = o.step_field(j1, dt, eps, WIL, st["ps"], psdt)
+    for n, d in (("vor", vordt), ("div", divdt), ("t", tdt), ("tr", trdt)):
+        new[n], _ = o.step_field(j1, dt, eps, WIL, st[n], d)
+    return new, {"U": U, "V": V, "PL": PL, "phi": phi}
+
+
+@pytest.mark.parametrize("tag", ["t30", "t63k16"])
+def test_dynamical_core_step_graph(tag, oracle_factory):
+    """SURVEY s8 f3 + f2: a COMPLETE adiabatic time step of the dynamical core on device-resident state, captured into one
+    graph -- inverse batch (+ grad -> grid), grid-space dynamical tendencies (tendencies.f90:105-197), direct batch,
+    tendency combination, spectral tendencies, implicit correction, diffusion block, leapfrog/RAW -- replayed for two
+    steps against the oracle's call-by-call sequence.  Only get_physical_tendencies (column physics, out of scope) is
+    missing from the reference's step()."""
+    import torch
+    kx = VARIANTS[tag][3]
+    sp, o = make_plan(tag, 4 * kx + 4), oracle_factory(tag)
+    nx, mx, il, ix = sp.nx, sp.mx, sp.il, sp.ix
+    dt = 2400.0
+    sp.initialize_implicit(dt); o.tail_init(dt)
+    st = state(sp, 8000)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    D = {n: dev(st[n]) for n in st}
+    P = 3 * kx
+    c128 = lambda *shape: torch.zeros(shape, dtype=torch.complex128, device="cuda")
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device="cuda")
+    ug, vg, plain_g = f64(kx, il, ix), f64(kx, il, ix), f64(4 * kx, il, ix)     # plain = vorg | divg | tg | trg
+    px, py = f64(1, il, ix), f64(1, il, ix)
+    U, V, PL = f64(P, il, ix), f64(P, il, ix), f64(P + 1, il, ix)
+    pvor, pdiv, pspec, phi = c128(P, nx, mx), c128(P, nx, mx), c128(P + 1, nx, mx), c128(kx, nx, mx)
+    spec_plain = c128(4 * kx, nx, mx)
+    sp.use_own_stream()
+    torch.cuda.synchronize()
+    with sp.graph_capture() as g:
+        sp.inverse_batch_dev(D["vor"][1], D["div"][1], ug, vg, spec_plain, plain_g, kcos_pairs=2, kcos=1)
+        sp.grad_to_grid_dev(D["ps"][1:2], px, py, 2)
+        sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
+        sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
+        sp.tendency_combine_dev(pdiv, pspec)
+        vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
+        sp.spectral_tendencies_dev(D["div"][0], D["t"][0], D["ps"][0], D["phis"], divdt, tdt, psdt, phi)
+        sp.implicit_terms_dev(divdt, tdt, psdt)
+        sp.hdiff_step_dev(D["vor"][0], D["div"][0], D["t"][0], D["tr"][0], D["tcorh"], D["qcorh"], SDRAG, vordt, divdt, tdt, trdt)
+        sp.step_fields_dev([(D["ps"], psdt), (D["vor"], vordt), (D["div"], divdt), (D["t"], tdt), (D["tr"], trdt)], 2, dt, ROB, WIL)
+    ref = st
+    for step in range(2):
+        spec_plain.copy_(torch.cat([D[n][1] for n in ("vor", "div", "t", "tr")]))
+        torch.cuda.synchronize()
+        g.launch()
+        sp.synchronize()
+        ref, out = oracle_dynamics_step(o, ref, 2, dt, ROB)
+        ok(U.cpu().numpy(), out["U"]); ok(V.cpu().numpy(), out["V"]); ok(PL.cpu().numpy(), out["PL"])
+        ok(phi.cpu().numpy(), out["phi"])
+        for n in ("ps", "vor", "div", "t", "tr"):
+            ok(D[n].cpu().numpy(), ref[n], 5e-12)          # five chained transforms + cancellation in the tendencies
+    g.close()
+    sp.close()
