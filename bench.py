@@ -140,6 +140,52 @@ def _time_us(torch, sp, fn, reps=20, warm=3):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
+    import numpy as np
+    sp = s.Spectral(res, kx=kx, max_batch=4 * kx + 4, device=dev.index or 0)
+    if kx not in (5, 7, 8):
+        sp.set_sigma(synth.SIGMA_L16 if kx == 16 else np.linspace(0.0, 1.0, kx + 1))
+    sp.initialize_implicit(2400.0)
+    nx, mx, il, ix, P = sp.nx, sp.mx, sp.il, sp.ix, 3 * kx
+    prog = lambda first, sc: torch.from_numpy((synth.spectra(2 * kx, sp.trunc, first=first) * sc).reshape(2, kx, nx, mx)).to(dev)
+    D = {"vor": prog(1, 1e-5), "div": prog(100, 1e-6), "t": prog(200, 3.0), "tr": prog(300, 1e-3)}
+    D["t"][:, :, 0, 0] += 250.0 * 2 ** 0.5
+    D["ps"] = torch.from_numpy((synth.spectra(2, sp.trunc, first=400) * 0.01).reshape(2, nx, mx)).to(dev)
+    one = lambda first, sc: torch.from_numpy(synth.spectra(1, sp.trunc, first=first)[0] * sc).to(dev)
+    phis, tcorh, qcorh = one(500, 100.0), one(600, 1.0), one(700, 1e-4)
+    c128 = lambda *sh: torch.zeros(sh, dtype=torch.complex128, device=dev)
+    f64 = lambda *sh: torch.zeros(sh, dtype=torch.float64, device=dev)
+    ug, vg, pg, px, py = f64(kx, il, ix), f64(kx, il, ix), f64(4 * kx, il, ix), f64(1, il, ix), f64(1, il, ix)
+    U, V, PL = f64(P, il, ix), f64(P, il, ix), f64(P + 1, il, ix)
+    pvor, pdiv, pspec, phi, splain = c128(P, nx, mx), c128(P, nx, mx), c128(P + 1, nx, mx), c128(kx, nx, mx), c128(4 * kx, nx, mx)
+    rob, wil, sdrag = float(np.float32(0.05)), float(np.float32(0.53)), 1.0 / (720.0 * 3600.0)
+    sp.use_own_stream()
+    torch.cuda.synchronize()
+    with sp.graph_capture() as g:
+        sp.inverse_batch_dev(D["vor"][1], D["div"][1], ug, vg, splain, pg, kcos_pairs=2, kcos=1)
+        sp.grad_to_grid_dev(D["ps"][1:2], px, py, 2)
+        sp.grid_tendencies_dev(ug, vg, pg[2 * kx:3 * kx], pg[:kx], pg[kx:2 * kx], pg[3 * kx:], px, py, U, V, PL)
+        sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
+        sp.tendency_combine_dev(pdiv, pspec)
+        vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
+        sp.spectral_tendencies_dev(D["div"][0], D["t"][0], D["ps"][0], phis, divdt, tdt, psdt, phi)
+        sp.implicit_terms_dev(divdt, tdt, psdt)
+        sp.hdiff_step_dev(D["vor"][0], D["div"][0], D["t"][0], D["tr"][0], tcorh, qcorh, sdrag, vordt, divdt, tdt, trdt)
+        sp.step_fields_dev([(D["ps"], psdt), (D["vor"], vordt), (D["div"], divdt), (D["t"], tdt), (D["tr"], trdt)], 2, 2400.0, rob, wil)
+    for _ in range(5):
+        g.launch()
+    sp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.launch()
+    sp.synchronize()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    g.close(); sp.close()
+    # timing only (synthetic state, the plain-field gather of a real host is not part of the graph); parity of this exact
+    # sequence is tests/test_gpu_step.py::test_dynamical_core_step_graph
+    return {"us_per_step": us, "launches_in_graph": 9, "transforms": 6 * kx + 2 + 9 * kx + 1, "levels": kx}
+
+
 def extras(s, torch, synth, sp, dev, args):
     """Side measurements the N=1 line carries outside `value`: the kernels a real model step uses
     (operator-fused and mixed-batch modes, model-shaped batch sizes) and the other resolution."""
@@ -173,6 +219,13 @@ def extras(s, torch, synth, sp, dev, args):
         us = _time_us(torch, sp, lambda: sp.direct_batch_dev(ug[:24], vg[:24], vor[:24], div[:24], pl_g[:25], pl_s[:25]), reps=50)
         out["direct_73"] = {"fields": 73, "us_per_launch": us, "fields_per_s": 73 / (us * 1e-6)}
         del ug, vg, vor, div, pl_s, pl_g
+    # a complete adiabatic dynamical-core step (tendencies.f90:11-41 + time_stepping.f90:35-118 minus column physics) on
+    # device-resident state, replayed as ONE graph: T30 L8 and BASELINE config 5 (T63 L16)
+    for tag, res_, kx_ in (("dynamics_step_t30_l8", "t30", 8), ("dynamics_step_t63_l16", "t63", 16)):
+        try:
+            out[tag] = dynamics_step_time(s, torch, synth, res_, kx_, dev)
+        except Exception as e:
+            out[tag] = {"error": repr(e)}
     # the other BASELINE resolution, same definition of a round trip (config 4: T63, B = 1536)
     other = "t63" if sp.trunc == 30 else "t30"
     nb2 = 1536 if other == "t63" else 6144
