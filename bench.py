@@ -11,10 +11,14 @@ N > 1 (torchrun, one rank per GPU): the batch index (field x level) is sharded, 
 transforms its own B fields, no data-path collective -> weak scaling; value = all ranks' round
 trips / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     : dominant kernel's algorithmic bytes per launch / its HIP-event launch time
-  cpu_baseline : the reference's own CPU path (oracle/_ref, flang build) -- or the C port if
-                 that is absent -- timed on ONE host core on a bounded sample of the same fields
+Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
+  roofline               : dominant kernel's algorithmic bytes per launch / its HIP-event launch time
+  cpu_baseline           : the reference's own CPU path (oracle/_ref, flang -O2 build = the parity oracle) -- or the C
+                           port if that is absent -- timed on ONE host core on a bounded sample of the same fields
+  cpu_baseline_fast_math : the same with the -O3 -ffast-math build (upstream compiles -Ofast)
+  cpu_baseline_socket    : one pinned process per physical core of ONE socket (CPU model and core count stated)
+  extras                 : (N = 1) the kernels a model step really uses -- operator-fused and mixed-batch launches,
+                           model-shaped batch sizes, a complete dynamical-core step as one graph -- and the T63 line
 """
 import argparse
 import json
