@@ -202,6 +202,14 @@ int spdy_grid_tendencies_dev(spdy_plan *plan, const double *ug, const double *vg
                              const double *divg, const double *trg, const double *px, const double *py, double *u_out,
                              double *v_out, double *plain_out);
 int spdy_tendency_combine_dev(spdy_plan *plan, double *pdiv, double *pspec);
+/* Everything after the direct batch in ONE launch (kx <= 16; the separate kernels otherwise): spdy_tendency_combine_dev,
+ * spdy_spectral_tendencies_dev, spdy_implicit_terms_dev, spdy_hdiff_step_dev and spdy_step_fields_dev of ps, vor, div, t, tr,
+ * with bit-identical results.  pvor/pdiv/pspec: the direct batch's outputs (the final, truncated tendencies are left in
+ * them); vor, div, t, tr: (mx,nx,kx,2), ps: (mx,nx,2) -- time level 1 feeds the spectral tendencies and the diffusion, as
+ * in the reference's leapfrog step (tendencies.f90:34-38 with alph >= 0.5, time_stepping.f90:63-96).                    */
+int spdy_spectral_step_dev(spdy_plan *plan, double *pvor, double *pdiv, double *pspec, double *vor, double *div, double *t,
+                           double *tr, double *ps, const double *phis, const double *d_tcorh, const double *d_qcorh, double sdrag,
+                           int j1, double dt, double eps, double wil, double *phi);
 
 /* ---- multi-GPU: the one exchange a level-sharded step needs (one process per GPU, RCCL over xGMI) ------------
  * The transform batch shards over (field x level) with no communication.  implicit_terms couples all levels of a

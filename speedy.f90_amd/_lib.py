@@ -75,6 +75,7 @@ SIGNATURES = {
     "spdy_implicit_terms_sharded_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
     "spdy_grid_tendencies_dev": [c_void_p] * 12,
     "spdy_tendency_combine_dev": [c_void_p, c_void_p, c_void_p],
+    "spdy_spectral_step_dev": [c_void_p] * 12 + [c_double, c_int, c_double, c_double, c_double, c_void_p],
     "spdy_output_workspace": [c_void_p],
     "spdy_output_batch_dev": [c_void_p] * 13,
     "spdy_graph_begin": [c_void_p],

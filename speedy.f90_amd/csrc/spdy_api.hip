@@ -246,6 +246,7 @@ int upload_all(spdy_plan *p)
         if ((rc = dev_alloc(p, e.n * sizeof(double), &ptr))) return rc;
         *e.dst = static_cast<double *>(ptr);
     }
+    for (int i = 0; i < 6; ++i) d.dmp_t[i] = p->d_dmp[i];
     d.xd = p->d_xd; d.xc = p->d_xc; d.xj = p->d_xj; d.tref1 = p->d_tref1; d.dhsx = p->d_dhsx; d.elz = p->d_elz;
     const double *lt = p->d_levtab;
     d.dhs = lt; d.dhsr = lt + kx; d.fsgr = lt + 2 * kx; d.tref = lt + 3 * kx; d.tref2 = lt + 4 * kx; d.tref3 = lt + 5 * kx;
@@ -367,7 +368,10 @@ bool use_fused(const spdy_plan *p, int nb)
 }
 // T63: fused field-pair kernels for the plain transforms (spdy_fused_t63.inc); the operator-fused modes use the
 // multi-kernel sequences
-bool use_fused63(const spdy_plan *p) { return p->tab.trunc == 63 && p->fused_mode != 0 && getenv("SPDY_NO_FUSED63") == nullptr; }
+// Below ~80 fields a launch is one field pair per workgroup on a fraction of the CUs and costs the pair's pipeline latency
+// (28-30 us, tools/t63_small_batch.py); the four-kernel path spreads such a batch over more workgroups (20-24 us), so
+// "auto" takes it there; spdy_plan_set_fused(1) forces the fused kernels at any size.
+bool use_fused63(const spdy_plan *p, int nb) { return p->tab.trunc == 63 && p->fused_mode != 0 && (nb >= 80 || p->fused_mode == 1); }
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
@@ -556,7 +560,7 @@ int spdy_spec_to_grid_dev(spdy_plan *p, int nb, const double *d_spec, const int 
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu * p->wg_per_cu, p->stream);
         });
-    if (use_fused63(p))
+    if (use_fused63(p, nb))
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused_t63(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu, p->stream);
         });
@@ -575,7 +579,7 @@ int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_
         return timed(p, SPDY_K_G2S_FUSED, [&] {
             return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu * p->wg_per_cu, p->stream);
         });
-    if (use_fused63(p))
+    if (use_fused63(p, nb))
         return timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu, p->stream); });
     RC(ensure_four(p));
     RC(timed(p, SPDY_K_FOURIER_DIR, [&] { return spdy::launch_fourier_dir(p->dev, nb, d_grid, nullptr, p->four, p->stream); }));
@@ -778,7 +782,7 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
         KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
         return SPDY_OK;
     }
-    if (use_fused63(p)) {                       // two scaled fused transforms + vds
+    if (use_fused63(p, nb)) {                   // two scaled fused transforms + vds
         RC(ensure_four(p));
         KERNEL(spdy::launch_g2s_fused_t63(p->dev, nb, ug, sc, p->tmp_c, p->num_cu, p->stream));
         KERNEL(spdy::launch_g2s_fused_t63(p->dev, nb, vg, sc, p->tmp_d, p->num_cu, p->stream));

@@ -236,6 +236,33 @@ int spdy_tendency_combine_dev(spdy_plan *p, double *pdiv, double *pspec)
     return SPDY_OK;
 }
 
+int spdy_spectral_step_dev(spdy_plan *p, double *pvor, double *pdiv, double *pspec, double *vor, double *div, double *t, double *tr,
+                           double *ps, const double *phis, const double *d_tcorh, const double *d_qcorh, double sdrag, int j1, double dt,
+                           double eps, double wil, double *phi)
+{
+    NEED_DEVICE(p);
+    if (!p->tab.implicit_ready) return fail(SPDY_ERR_STATE, "spectral_step needs spdy_implicit_init first");
+    if (!p->tab.sigma_ready) return fail(SPDY_ERR_STATE, "spectral_step needs sigma levels");
+    if (!pvor || !pdiv || !pspec || !vor || !div || !t || !tr || !ps || !phis || !d_tcorh || !d_qcorh || !phi)
+        return fail(SPDY_ERR_ARG, "null device pointer");
+    if (j1 != 1 && j1 != 2) return fail(SPDY_ERR_ARG, "j1 must be 1 or 2");
+    const int kx = p->tab.kx;
+    if (kx > 16) {   // the fused kernel holds one level per thread row (64 x kx <= 1024 threads): issue the separate kernels
+        RC(spdy_tendency_combine_dev(p, pdiv, pspec));
+        const size_t L = (size_t)kx * spec_elems(p);
+        double *divdt = pdiv, *tdt = pdiv + L, *trdt = pdiv + 2 * L, *psdt = pspec + 3 * L;
+        RC(spdy_spectral_tendencies_dev(p, div, t, ps, phis, divdt, tdt, psdt, phi));
+        RC(spdy_implicit_terms_dev(p, divdt, tdt, psdt));
+        RC(spdy_hdiff_step_dev(p, vor, div, t, tr, d_tcorh, d_qcorh, sdrag, pvor, divdt, tdt, trdt));
+        const spdy_step_op ops[5] = {{1, ps, psdt}, {kx, vor, pvor}, {kx, div, divdt}, {kx, t, tdt}, {kx, tr, trdt}};
+        return spdy_step_fields_dev(p, 5, ops, j1, dt, eps, wil);
+    }
+    const spdy::SpecStep a{pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, sdrag, dt, eps, wil, j1,
+                           p->tab.ix == 4 * p->tab.iy};
+    KERNEL(spdy::launch_spectral_step(p->dev, a, p->stream));
+    return SPDY_OK;
+}
+
 /* ---------------------------------------------------------------- output path */
 int spdy_output_workspace(spdy_plan *p)
 {

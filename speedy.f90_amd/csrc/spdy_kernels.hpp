@@ -33,6 +33,7 @@ struct DevPlan {
     // horizontal_diffusion.f90:70-82) and the reference temperature profile (implicit.f90:62-67);
     // rgtref = rgas*tref.  tref* are filled by spdy_implicit_init, the others whenever sigma levels exist.
     const double *dhs, *dhsr, *fsgr, *tref, *tref2, *tref3, *rgtref, *xgeop1, *xgeop2, *corf, *tcorv, *qcorv;
+    const double *dmp_t[6]; // dmp, dmpd, dmps, dmp1, dmp1d, dmp1s [nx][mx] (dmp1* valid after spdy_implicit_init)
     const double *coriol;   // [il] 2*omega*sin(lat) (geometry.f90:89), southernmost row first
     double rgas, akap;      // physical_constants.f90:22-24 (float32 literals widened)
 };
@@ -124,6 +125,16 @@ struct GridTend {
 };
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
 hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec, hipStream_t s);
+// the whole spectral-space tail of a step in one launch (kx <= 16)
+struct SpecStep {
+    double *pvor, *pdiv, *pspec;                 // direct-batch outputs [3kx], [3kx], [3kx+1]; tendencies are left in them
+    double *vor, *div, *t, *tr, *ps;             // prognostics, both time levels ([2][kx] / [2])
+    const double *phis, *tcorh, *qcorh;
+    double *phi;
+    double sdrag, dt, eps, wil;
+    int j1, do_trunct;
+};
+hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s);
 // output path (input_output.f90:184-206)
 struct GatherOps { int nops, nfld[8]; const double *src[8]; double *dst[8]; };
 hipError_t launch_gather_spectra(const DevPlan &p, const GatherOps &g, hipStream_t s);

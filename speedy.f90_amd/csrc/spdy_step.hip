@@ -343,6 +343,147 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 }
 
 // ------------------------------------------------------------------------------------------
+// The whole spectral-space tail of a time step in ONE launch: tendency combination (tendencies.f90:125-126, 218-233),
+// get_spectral_tendencies (:242-293), implicit_terms (implicit.f90:168-217), the diffusion block and step_field_*
+// (time_stepping.f90:62-167).  At model sizes each of the five kernels above is a ~6 us launch around a few hundred KB;
+// fused, the tendencies never leave the CU between them.  Block = 64 coefficients x kx level rows (kx <= 16): thread
+// (e, k) owns the tendencies of one coefficient at one level in registers; the level-coupled parts (vertical sums,
+// geopotential recursion, the kx x kx mat-vecs) go through LDS.  Every expression is the one of the separate kernel, so
+// the results are bit-identical to the unfused sequence.
+// ------------------------------------------------------------------------------------------
+__global__ void spectral_step_kernel(DevPlan p, SpecStep a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];           // [4][kx][64] complex: divdt, tdt, yf / d, scratch
+    const int kx = p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
+    const int e = blockIdx.x * 64 + tx;
+    const bool valid = e < sz;
+    const int ec = valid ? e : sz - 1, m = ec % p.mx, n = ec / p.mx, l = m + n;
+    const long i = (long)k * sz + ec;                                     // this thread's (level, coefficient)
+    double *sdiv = sm, *stdt = sm + (size_t)kx * 128, *sy = sm + (size_t)kx * 256;
+    auto at = [&](double *b, int kk) { return b + ((size_t)kk * 64 + tx) * 2; };
+    auto get = [&](double *b, int kk) { return cpx{at(b, kk)[0], at(b, kk)[1]}; };
+    auto put = [&](double *b, int kk, cpx z) { at(b, kk)[0] = z.re; at(b, kk)[1] = z.im; };
+    // ---- tendency combination on the direct batch's outputs
+    cpx vordt = ld(a.pvor, i);
+    cpx divdt = ld(a.pdiv, i) - p.el2[ec] * (-ld(a.pspec, i));
+    cpx tdt = ld(a.pdiv, (long)kx * sz + i) + ld(a.pspec, (long)kx * sz + i);
+    cpx trdt = ld(a.pdiv, (long)2 * kx * sz + i) + ld(a.pspec, (long)2 * kx * sz + i);
+    put(sdiv, k, divdt);
+    put(stdt, k, tdt);
+    __syncthreads();
+    // ---- get_spectral_tendencies: one thread per coefficient walks the levels (time level 1 of div, t, ps)
+    cpx psdt = {0.0, 0.0};
+    if (k == 0) {
+        psdt = ld(a.pspec, (long)3 * kx * sz + ec);
+        if (ec == 0) psdt = {0.0, 0.0};                                    // tendencies.f90:126
+        cpx dmean = {0.0, 0.0};
+        for (int kk = 0; kk < kx; ++kk) dmean = dmean + p.dhs[kk] * ld(a.div, (long)kk * sz + ec);
+        psdt = psdt - dmean;
+        if (ec == 0) psdt = {0.0, 0.0};
+        cpx sig = {0.0, 0.0}, dumk = {0.0, 0.0};
+        for (int kk = 0; kk < kx; ++kk) {
+            cpx sig1 = {0.0, 0.0}, dumk1 = {0.0, 0.0};
+            if (kk < kx - 1) {
+                sig1 = sig - p.dhs[kk] * (ld(a.div, (long)kk * sz + ec) - dmean);
+                dumk1 = (p.tref[kk + 1] - p.tref[kk]) * sig1;
+            }
+            put(stdt, kk, ((get(stdt, kk) - p.dhsr[kk] * (dumk1 + dumk)) + p.tref3[kk] * (sig1 + sig)) - p.tref2[kk] * dmean);
+            sig = sig1;
+            dumk = dumk1;
+        }
+        if (valid) geopotential_column(p, ec, sz, m == 0, a.t, ld(a.phis, ec), a.phi);
+        const cpx psv = ld(a.ps, ec);
+        const double l2 = p.el2[ec];
+        for (int kk = 0; kk < kx; ++kk) {
+            // (phi is re-read from global by the thread that just wrote it)
+            const cpx x = (valid ? ld(a.phi, (long)kk * sz + ec) : cpx{0.0, 0.0}) + p.rgtref[kk] * psv;
+            put(sdiv, kk, get(sdiv, kk) - l2 * (-x));
+        }
+    }
+    __syncthreads();
+    // ---- implicit_terms
+    const double ez = p.elz[ec];
+    {   // psdt lives with thread k == 0: broadcast through LDS scratch slot 0 of sy's fourth plane
+        double *sps = sm + (size_t)kx * 384;
+        if (k == 0) { sps[2 * tx] = psdt.re; sps[2 * tx + 1] = psdt.im; }
+        __syncthreads();
+        const cpx ps0 = {sps[2 * tx], sps[2 * tx + 1]};
+        cpx ye = {0.0, 0.0};
+        for (int k1 = 0; k1 < kx; ++k1) ye = ye + p.xd[k + kx * k1] * get(stdt, k1);
+        ye = ye + p.tref1[k] * ps0;
+        put(sy, k, get(sdiv, k) + ez * ye);                                // yf
+        __syncthreads();
+        cpx d = {0.0, 0.0};
+        if (l != 0) {
+            const double *xj = p.xj + (long)kx * kx * (l - 1);
+            for (int k1 = 0; k1 < kx; ++k1) d = d + xj[k + kx * k1] * get(sy, k1);
+        }
+        __syncthreads();
+        put(sy, k, d);                                                     // divdt after the solve
+        __syncthreads();
+        if (k == 0) {
+            cpx ps = ps0;
+            for (int kk = 0; kk < kx; ++kk) ps = ps - p.dhsx[kk] * get(sy, kk);
+            psdt = ps;
+        }
+        cpx t = get(stdt, k);
+        for (int k1 = 0; k1 < kx; ++k1) t = t + p.xc[k + kx * k1] * get(sy, k1);
+        tdt = t;
+        divdt = d;
+    }
+    if (!valid) return;
+    // ---- diffusion block of step() (time level 1 of the prognostics)
+    {
+        const double dmp = p.dmp_t[0][ec], dmpd = p.dmp_t[1][ec], dmps = p.dmp_t[2][ec];
+        const double dmp1 = p.dmp_t[3][ec], dmp1d = p.dmp_t[4][ec], dmp1s = p.dmp_t[5][ec];
+        const cpx vo = ld(a.vor, i), dv = ld(a.div, i);
+        vordt = hd(vo, vordt, dmp, dmp1);
+        divdt = hd(dv, divdt, dmpd, dmp1d);
+        const cpx ctmp = ld(a.t, i) + p.tcorv[k] * ld(a.tcorh, ec);
+        tdt = hd(ctmp, tdt, dmp, dmp1);
+        if (m == 0 && k == 0) {
+            vordt = vordt - a.sdrag * vo;
+            divdt = divdt - a.sdrag * dv;
+        }
+        vordt = hd(vo, vordt, dmps, dmp1s);
+        divdt = hd(dv, divdt, dmps, dmp1s);
+        tdt = hd(ctmp, tdt, dmps, dmp1s);
+        const cpx cq = ld(a.tr, i) + p.qcorv[k] * ld(a.qcorh, ec);
+        trdt = hd(cq, trdt, dmpd, dmp1d);
+    }
+    // ---- step_field_3d for vor, div, t, tr and step_field_2d for ps; tendencies written back truncated, as the
+    // separate kernels leave them
+    const double trf = p.trfilt[ec];
+    const long lvl2 = (long)kx * sz;
+    auto stepf = [&](double *f, long idx, long off2, cpx fd, double *fdt_out, long fdt_idx) {
+        if (a.do_trunct) fd = trf * fd;
+        st(fdt_out, fdt_idx, fd);
+        const cpx o1 = ld(f, idx), o2 = ld(f, off2 + idx);
+        const cpx fnew = o1 + a.dt * fd;
+        const cpx oj = a.j1 == 1 ? o1 : o2;
+        const cpx n1 = oj + (a.wil * a.eps) * ((o1 - 2.0 * oj) + fnew);
+        const cpx oj2 = a.j1 == 1 ? n1 : o2;
+        const cpx n2 = fnew - ((1.0 - a.wil) * a.eps) * ((n1 - 2.0 * oj2) + fnew);
+        st(f, idx, n1);
+        st(f, off2 + idx, n2);
+    };
+    stepf(a.vor, i, lvl2, vordt, a.pvor, i);
+    stepf(a.div, i, lvl2, divdt, a.pdiv, i);
+    stepf(a.t, i, lvl2, tdt, a.pdiv, (long)kx * sz + i);
+    stepf(a.tr, i, lvl2, trdt, a.pdiv, (long)2 * kx * sz + i);
+    if (k == 0) stepf(a.ps, ec, sz, psdt, a.pspec, (long)3 * kx * sz + ec);
+}
+
+hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s)
+{
+    const int sz = p.mx * p.nx;
+    if (p.kx > 16) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)3 * p.kx * 64 + 64) * 16;
+    hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Output path (input_output.f90:184-206): after the 5 kx + 1 inverse transforms, the gridded fields are scaled and
 // rounded to float32.  gather_spectra packs the separately stored plain spectra (t, q, phi levels and ps) into one
 // stack so that the whole snapshot is ONE transform launch; output_cast does the float32 epilogue.

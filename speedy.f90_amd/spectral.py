@@ -376,6 +376,14 @@ class Spectral:
         self._sync_stream()
         check(self.lib.spdy_tendency_combine_dev(self.h, self._dp(pdiv), self._dp(pspec)))
 
+    def spectral_step_dev(self, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, tcorh, qcorh, sdrag, j1, dt, eps, wil, phi):
+        """Everything after the direct batch in one launch: tendency_combine, spectral_tendencies, implicit_terms, hdiff_step
+        and step_fields of ps, vor, div, t, tr (prognostics [2,kx,nx,mx] / ps [2,nx,mx], both time levels)."""
+        self._sync_stream()
+        args = (pvor, pdiv, pspec, vor, div, t, tr, ps, phis, tcorh, qcorh)
+        check(self.lib.spdy_spectral_step_dev(self.h, *[self._dp(x) for x in args], float(sdrag), int(j1), float(dt), float(eps),
+                                              float(wil), self._dp(phi)))
+
     def output_batch_dev(self, vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out):
         """input_output.f90:184-206 on device-resident state: complex128 [kx,nx,mx] (ps [nx,mx]) in, float32 [kx,il,ix]
         (ps_out [il,ix]) out."""

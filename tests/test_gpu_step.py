@@ -259,8 +259,9 @@ def oracle_dynamics_step(o, st, j1, dt, eps):
     return new, {"U": U, "V": V, "PL": PL, "phi": phi}
 
 
+@pytest.mark.parametrize("one_launch_tail", [False, True])
 @pytest.mark.parametrize("tag", ["t30", "t63k16"])
-def test_dynamical_core_step_graph(tag, oracle_factory):
+def test_dynamical_core_step_graph(tag, one_launch_tail, oracle_factory):
     """SURVEY s8 f3 + f2: a COMPLETE adiabatic time step of the dynamical core on device-resident state, captured into one
     graph -- inverse batch (+ grad -> grid), grid-space dynamical tendencies (tendencies.f90:105-197), direct batch,
     tendency combination, spectral tendencies, implicit correction, diffusion block, leapfrog/RAW -- replayed for two
@@ -290,12 +291,16 @@ def test_dynamical_core_step_graph(tag, oracle_factory):
         sp.grad_to_grid_dev(D["ps"][1:2], px, py, 2)
         sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
         sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
-        sp.tendency_combine_dev(pdiv, pspec)
-        vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
-        sp.spectral_tendencies_dev(D["div"][0], D["t"][0], D["ps"][0], D["phis"], divdt, tdt, psdt, phi)
-        sp.implicit_terms_dev(divdt, tdt, psdt)
-        sp.hdiff_step_dev(D["vor"][0], D["div"][0], D["t"][0], D["tr"][0], D["tcorh"], D["qcorh"], SDRAG, vordt, divdt, tdt, trdt)
-        sp.step_fields_dev([(D["ps"], psdt), (D["vor"], vordt), (D["div"], divdt), (D["t"], tdt), (D["tr"], trdt)], 2, dt, ROB, WIL)
+        if one_launch_tail:      # the five spectral-space kernels below as ONE launch (spdy_spectral_step_dev)
+            sp.spectral_step_dev(pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"],
+                                 SDRAG, 2, dt, ROB, WIL, phi)
+        else:
+            sp.tendency_combine_dev(pdiv, pspec)
+            vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
+            sp.spectral_tendencies_dev(D["div"][0], D["t"][0], D["ps"][0], D["phis"], divdt, tdt, psdt, phi)
+            sp.implicit_terms_dev(divdt, tdt, psdt)
+            sp.hdiff_step_dev(D["vor"][0], D["div"][0], D["t"][0], D["tr"][0], D["tcorh"], D["qcorh"], SDRAG, vordt, divdt, tdt, trdt)
+            sp.step_fields_dev([(D["ps"], psdt), (D["vor"], vordt), (D["div"], divdt), (D["t"], tdt), (D["tr"], trdt)], 2, dt, ROB, WIL)
     ref = st
     for step in range(2):
         spec_plain.copy_(torch.cat([D[n][1] for n in ("vor", "div", "t", "tr")]))
