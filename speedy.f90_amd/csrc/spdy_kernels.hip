@@ -817,12 +817,14 @@ static size_t legendre_dir_lds(const DevPlan &p) { return sizeof(double) * std::
 hipError_t prepare_device_kernels()
 {
     struct { const void *fn; int bytes; } big[] = {
-        {reinterpret_cast<const void *>(s2g_fused_t30_kernel<0>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<1>), t30::S2G_LDS},
-        {reinterpret_cast<const void *>(s2g_fused_t30_kernel<2>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<3>), t30::S2G_LDS},
-        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<0>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<1>), t30::G2S_LDS},
-        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<2>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<3>), t30::G2S_LDS},
-        {reinterpret_cast<const void *>(s2g_fused_t63_kernel), t63::LDS_BYTES},
-        {reinterpret_cast<const void *>(g2s_fused_t63_kernel<0>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(g2s_fused_t63_kernel<1>), t63::LDS_BYTES},
+#define SPDY_K2(k_, m_, b_) {reinterpret_cast<const void *>(k_<m_, false>), b_}, {reinterpret_cast<const void *>(k_<m_, true>), b_}
+        SPDY_K2(s2g_fused_t30_kernel, 0, t30::S2G_LDS), SPDY_K2(s2g_fused_t30_kernel, 1, t30::S2G_LDS),
+        SPDY_K2(s2g_fused_t30_kernel, 2, t30::S2G_LDS), SPDY_K2(s2g_fused_t30_kernel, 3, t30::S2G_LDS),
+        SPDY_K2(g2s_fused_t30_kernel, 0, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 1, t30::G2S_LDS),
+        SPDY_K2(g2s_fused_t30_kernel, 2, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 3, t30::G2S_LDS),
+        SPDY_K2(g2s_fused_t63_kernel, 0, t63::LDS_BYTES), SPDY_K2(g2s_fused_t63_kernel, 1, t63::LDS_BYTES),
+#undef SPDY_K2
+        {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(s2g_fused_t63_kernel<true>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {
         hipError_t e = hipFuncSetAttribute(b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.bytes);
