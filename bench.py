@@ -254,9 +254,9 @@ def extras(s, torch, synth, sp, dev, args):
     def rt():
         sp2.grid_to_spec_dev(g2, s2)
         sp2.spec_to_grid_dev(s2, o2, kcos=1)
-    us = _time_us(torch, sp2, rt, reps=30, warm=10)
+    us = _time_us(torch, sp2, rt, reps=100, warm=60)   # (a fresh plan's first ~50 round trips run 15 % slow: clocks, first touch)
     sp2.set_profiling(True)
-    for _ in range(10):
+    for _ in range(20):
         rt()
     prof = {k: ms / max(c, 1) * 1e3 for k, (ms, c) in sp2.get_profile().items() if c}
     byt = 2 * nb2 * (sp2.ix * sp2.il * 8 + sp2.mx * sp2.nx * 16)

@@ -58,7 +58,7 @@ enum {
  * call on it returns SPDY_ERR_NO_DEVICE).
  * max_batch bounds nb of every batched call.  Device memory beyond the tables (< 10 MB) is allocated on demand:
  * the host-pointer entry points stage through 4 x max_batch grids from their first call on, the four-kernel path
- * (T63, or spdy_plan_set_fused(0)) keeps a Fourier workspace of max_batch x il x 2mx doubles.  Destroying a plan
+ * (T63 small batches, other resolutions, or spdy_plan_set_fused(0)) keeps a Fourier workspace of max_batch x il x 2mx doubles.  Destroying a plan
  * also invalidates the graphs captured from it (spdy_graph_launch then returns SPDY_ERR_STATE).          */
 enum { SPDY_MAX_KX = 32, SPDY_DEVICE_NONE = -1, SPDY_DEVICE_AUTO = -2 };
 int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan);
@@ -77,8 +77,12 @@ int spdy_plan_synchronize(spdy_plan *plan);
 enum { SPDY_K_LEGENDRE_INV = 0, SPDY_K_FOURIER_INV = 1, SPDY_K_FOURIER_DIR = 2, SPDY_K_LEGENDRE_DIR = 3,
        SPDY_K_S2G_FUSED = 4, SPDY_K_G2S_FUSED = 5, SPDY_K_COUNT = 6 };
 int spdy_plan_set_profiling(spdy_plan *plan, int on);
-/* Kernel selection for the transforms: 1 / -1 (default) = fused single-pass kernels where the resolution
- * has them (T30), 0 = force the four-kernel path (any resolution; what T63 always uses).          */
+/* Kernel selection for the transforms: 1 = fused single-pass kernels (T30, T63), 0 = the four-kernel path (any
+ * resolution), -1 (default) = fused, except T63 batches under 80 fields, which take the four-kernel path (lower
+ * latency there).  The two paths agree to rounding, not bitwise: pin 1 or 0 when a field's bits must not depend on
+ * the size of the batch it travels in.  Fused launches whose grid-side array is >= 16 MB stream it with
+ * non-temporal loads/stores (the data passes through the caches once); smaller ones leave it cached for their
+ * consumer.                                                                                        */
 int spdy_plan_set_fused(spdy_plan *plan, int mode);
 int spdy_plan_get_profile(spdy_plan *plan, double *ms, int *launches);
 /* dims[0..7] = trunc, ix, iy, il, kx, nx, mx, max_batch */

@@ -368,11 +368,12 @@ bool use_fused(const spdy_plan *p, int nb)
 }
 // T63: fused field-pair kernels for the plain transforms (spdy_fused_t63.inc); the operator-fused modes use the
 // multi-kernel sequences
-// The fused kernels serve every batch size at T63, so a field's result does not depend on the size or composition of the
-// batch it travels in (tests/test_gpu_determinism.py; a level-sharded run reproduces the single-GPU bits).  Below ~80 fields
-// a launch is one field pair per workgroup on a fraction of the CUs and costs the pair's pipeline latency (28-30 us,
-// tools/t63_small_batch.py); spdy_plan_set_fused(0) selects the four-kernel pipeline, which is faster there (20-24 us).
-bool use_fused63(const spdy_plan *p, int) { return p->tab.trunc == 63 && p->fused_mode != 0; }
+// Below ~80 fields a T63 launch is one field pair per workgroup on a fraction of the CUs and costs the pair's pipeline
+// latency (28-30 us, tools/t63_small_batch.py); the four-kernel pipeline spreads such a batch over more workgroups
+// (20-24 us), so "auto" takes it there (a T63 L16 model step: 311 -> 268 us).  The two paths agree to rounding, not
+// bitwise: spdy_plan_set_fused(1) (or 0) pins one path, and with it a field's bits, for every batch size
+// (tests/test_gpu_determinism.py).
+bool use_fused63(const spdy_plan *p, int nb) { return p->tab.trunc == 63 && p->fused_mode != 0 && (nb >= 80 || p->fused_mode == 1); }
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
