@@ -735,6 +735,13 @@ static int derived_to_grid(spdy_plan *p, int nb, int mode, const double *in0, co
         // rows of psdy that grad leaves untouched (l > trunc+1 inside row nx) are never read by the transform
         KERNEL(spdy::launch_grad(p->dev, nb, in0, p->tmp_c, p->tmp_d, p->stream));
     }
+    if (use_fused63(p, 2 * nb)) {               // both derived spectra in ONE fused launch (two segments)
+        spdy::T63Batch b{};
+        b.nseg = 2;
+        b.seg[0] = spdy::T63Seg{p->tmp_c, g0, nullptr, nullptr, nb, kcos, 0, 0};
+        b.seg[1] = spdy::T63Seg{p->tmp_d, g1, nullptr, nullptr, nb, kcos, 0, 0};
+        return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
+    }
     RC(spdy_spec_to_grid_dev(p, nb, p->tmp_c, nullptr, kcos, g0));
     RC(spdy_spec_to_grid_dev(p, nb, p->tmp_d, nullptr, kcos, g1));
     return SPDY_OK;
@@ -784,10 +791,13 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
         KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
         return SPDY_OK;
     }
-    if (use_fused63(p, nb)) {                   // two scaled fused transforms + vds
+    if (use_fused63(p, 2 * nb)) {               // both scaled transforms in ONE fused launch (two segments) + vds
         RC(ensure_four(p));
-        KERNEL(spdy::launch_g2s_fused_t63(p->dev, nb, ug, sc, p->tmp_c, p->num_cu, p->stream));
-        KERNEL(spdy::launch_g2s_fused_t63(p->dev, nb, vg, sc, p->tmp_d, p->num_cu, p->stream));
+        spdy::T63Batch b{};
+        b.nseg = 2;
+        b.seg[0] = spdy::T63Seg{ug, p->tmp_c, sc, nullptr, nb, 1, 0, 0};
+        b.seg[1] = spdy::T63Seg{vg, p->tmp_d, sc, nullptr, nb, 1, 0, 0};
+        RC(timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63_batch(p->dev, b, p->num_cu, p->stream); }));
         KERNEL(spdy::launch_vds(p->dev, nb, p->tmp_c, p->tmp_d, vorm, divm, p->stream));
         return SPDY_OK;
     }
@@ -813,6 +823,17 @@ int spdy_inverse_batch_dev(spdy_plan *p, int npairs, const double *vor, const do
             return spdy::launch_s2g_fused(p->dev, npairs, vor, nullptr, kcos_pairs, ug, p->num_cu * p->wg_per_cu, p->stream, 3, dv, vg,
                                           nplain, spec, d_kcos, kcos_all, grid);
         });
+    if (npairs > 0 && nplain > 0 && use_fused63(p, 2 * npairs + nplain)) {
+        // T63: uvspec, then the U, V and plain spectra as three segments of ONE fused launch
+        RC(ensure_four(p));
+        KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
+        spdy::T63Batch b{};
+        b.nseg = 3;
+        b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        b.seg[1] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        b.seg[2] = spdy::T63Seg{spec, grid, nullptr, d_kcos, nplain, kcos_all, 0, 0};
+        return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
+    }
     if (npairs) RC(spdy_uvspec_to_grid_dev(p, npairs, vor, dv, ug, vg, kcos_pairs));
     if (nplain) RC(spdy_spec_to_grid_dev(p, nplain, spec, d_kcos, kcos_all, grid));
     return SPDY_OK;
@@ -830,6 +851,19 @@ int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const doub
         return timed(p, SPDY_K_G2S_FUSED, [&] {
             return spdy::launch_g2s_fused(p->dev, npairs, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm, nplain, grid, spec);
         });
+    }
+    if (npairs > 0 && nplain > 0 && use_fused63(p, 2 * npairs + nplain)) {
+        // T63: the scaled u, v grids and the plain grids as three segments of ONE fused launch, then vds
+        RC(ensure_four(p));
+        const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
+        spdy::T63Batch b{};
+        b.nseg = 3;
+        b.seg[0] = spdy::T63Seg{ug, p->tmp_c, sc, nullptr, npairs, 1, 0, 0};
+        b.seg[1] = spdy::T63Seg{vg, p->tmp_d, sc, nullptr, npairs, 1, 0, 0};
+        b.seg[2] = spdy::T63Seg{grid, spec, nullptr, nullptr, nplain, 1, 0, 0};
+        RC(timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63_batch(p->dev, b, p->num_cu, p->stream); }));
+        KERNEL(spdy::launch_vds(p->dev, npairs, p->tmp_c, p->tmp_d, vorm, divm, p->stream));
+        return SPDY_OK;
     }
     if (npairs) RC(spdy_vdspec_dev(p, npairs, ug, vg, vorm, divm, kcos));
     if (nplain) RC(spdy_grid_to_spec_dev(p, nplain, grid, spec));

@@ -78,6 +78,22 @@ hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const 
 // Fused T63 kernels: a pair of fields per tile, six latitude chunks, accumulators / B operands resident in VGPRs
 hipError_t launch_s2g_fused_t63(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid, int max_wg,
                                 hipStream_t s);
+// One fused T63 launch over up to four independent sub-batches (own arrays, own scale / kcos policy); pair0 and npairs are
+// filled in by the launcher
+constexpr int T63_MAX_SEG = 4;
+struct T63Seg {
+    const double *src;
+    double *dst;
+    const double *scale;   // direct: per-latitude factor applied on load, or nullptr
+    const int *kcos;       // inverse: per-field kcos (device), or nullptr for kcos_all
+    int nb, kcos_all, pair0, pad;
+};
+struct T63Batch {
+    int nseg, npairs;
+    T63Seg seg[T63_MAX_SEG];
+};
+hipError_t launch_s2g_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
+hipError_t launch_g2s_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
 hipError_t launch_g2s_fused_t63(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg, hipStream_t s);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };

@@ -15,13 +15,15 @@ def ok(a, b, tol=TOL):
     assert synth.relerr(a, b) <= tol, synth.relerr(a, b)
 
 
-@pytest.mark.parametrize("res,nb", [("t30", 1), ("t30", 24), ("t30", 257), ("t63", 5)])
+@pytest.mark.parametrize("res,nb", [("t30", 1), ("t30", 24), ("t30", 257), ("t63", 5), ("t63f", 5), ("t63f", 1), ("t63", 41)])
 @pytest.mark.parametrize("kcos", [2, 1])
 def test_uvspec_and_grad_to_grid(res, nb, kcos, oracle_factory):
     import torch
     import speedy_f90_amd as s
-    o = oracle_factory(res)
-    sp = s.Spectral(res, kx=8, max_batch=max(nb, 8), device=0)
+    o = oracle_factory(res[:3])
+    sp = s.Spectral(res[:3], kx=8, max_batch=max(nb, 8), device=0)
+    if res.endswith("f"):
+        sp.set_fused(1)                                        # T63: operator kernel + ONE two-segment fused launch
     sp.use_torch_stream()
     S = synth.spectra(2 * nb, sp.trunc, first=700, full_rows=True)     # row nx populated: uvspec must not care
     vor, div = torch.from_numpy(S[:nb]).cuda(), torch.from_numpy(S[nb:]).cuda()
@@ -49,13 +51,14 @@ def test_uvspec_and_grad_to_grid(res, nb, kcos, oracle_factory):
     sp.close()
 
 
-@pytest.mark.parametrize("nb", [1, 3, 48, 300])
+@pytest.mark.parametrize("res,nb", [("t30", 1), ("t30", 3), ("t30", 48), ("t30", 300), ("t63", 1), ("t63", 7)])
 @pytest.mark.parametrize("kcos", [2, 1])
-def test_vdspec_one_pass(nb, kcos, oracle_factory):
+def test_vdspec_one_pass(res, nb, kcos, oracle_factory):
+    """fused = 1: one kernel at T30; at T63 ONE two-segment fused launch + vds.  fused = 0: five kernels."""
     import torch
     import speedy_f90_amd as s
-    o = oracle_factory("t30")
-    sp = s.Spectral("t30", kx=8, max_batch=max(nb, 8), device=0)
+    o = oracle_factory(res)
+    sp = s.Spectral(res, kx=8, max_batch=max(nb, 8), device=0)
     sp.use_torch_stream()
     G = synth.grids(2 * nb, sp.ix, sp.il, first=900)
     ug, vg = torch.from_numpy(G[:nb]).cuda(), torch.from_numpy(G[nb:]).cuda()
@@ -128,12 +131,16 @@ def test_hdiff_multi_equals_separate_calls(oracle_factory):
     sp.close()
 
 
-@pytest.mark.parametrize("res,npairs,nplain", [("t30", 24, 25), ("t30", 1, 1), ("t30", 3, 8), ("t30", 300, 301), ("t63", 3, 5)])
+@pytest.mark.parametrize("res,npairs,nplain", [("t30", 24, 25), ("t30", 1, 1), ("t30", 3, 8), ("t30", 300, 301), ("t63", 3, 5),
+                                               ("t63f", 3, 5), ("t63f", 1, 1), ("t63f", 48, 49)])
 def test_direct_batch_one_launch(res, npairs, nplain):
-    """spdy_direct_batch_dev = vdspec of the pairs + grid_to_spec of the plain fields, bit for bit."""
+    """spdy_direct_batch_dev = vdspec of the pairs + grid_to_spec of the plain fields, bit for bit.  t63f = fused kernels
+    pinned (spdy_plan_set_fused(1)): the batch is ONE three-segment launch (+ vds), as it is from 80 fields in auto mode."""
     import torch
     import speedy_f90_amd as s
-    sp = s.Spectral(res, kx=8, max_batch=max(npairs, nplain, 8), device=0)
+    sp = s.Spectral(res[:3], kx=8, max_batch=max(npairs, nplain, 8), device=0)
+    if res.endswith("f"):
+        sp.set_fused(1)
     G = torch.from_numpy(synth.grids(2 * npairs + nplain, sp.ix, sp.il, first=4000)).cuda()
     ug, vg, gp = G[:npairs], G[npairs:2 * npairs], G[2 * npairs:]
     cs = (sp.nx, sp.mx)
@@ -148,12 +155,16 @@ def test_direct_batch_one_launch(res, npairs, nplain):
     sp.close()
 
 
-@pytest.mark.parametrize("res,npairs,nplain", [("t30", 16, 59), ("t30", 1, 1), ("t30", 5, 2), ("t30", 300, 299), ("t63", 3, 5)])
+@pytest.mark.parametrize("res,npairs,nplain", [("t30", 16, 59), ("t30", 1, 1), ("t30", 5, 2), ("t30", 300, 299), ("t63", 3, 5),
+                                               ("t63f", 3, 5), ("t63f", 1, 1), ("t63f", 16, 64)])
 def test_inverse_batch_one_launch(res, npairs, nplain):
-    """spdy_inverse_batch_dev = uvspec_to_grid of the pairs + spec_to_grid of the plain fields (mixed kcos), bit for bit."""
+    """spdy_inverse_batch_dev = uvspec_to_grid of the pairs + spec_to_grid of the plain fields (mixed kcos), bit for bit.
+    t63f = fused kernels pinned: uvspec + ONE three-segment launch."""
     import torch
     import speedy_f90_amd as s
-    sp = s.Spectral(res, kx=8, max_batch=max(npairs, nplain, 8), device=0)
+    sp = s.Spectral(res[:3], kx=8, max_batch=max(npairs, nplain, 8), device=0)
+    if res.endswith("f"):
+        sp.set_fused(1)
     S = torch.from_numpy(synth.spectra(2 * npairs + nplain, sp.trunc, first=5000, full_rows=True)).cuda()
     vor, div, spl = S[:npairs], S[npairs:2 * npairs], S[2 * npairs:]
     kc = torch.tensor([1 + (i % 3 == 0) for i in range(nplain)], dtype=torch.int32, device="cuda")
