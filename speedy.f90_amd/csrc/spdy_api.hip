@@ -374,6 +374,9 @@ bool use_fused(const spdy_plan *p, int nb)
 // bitwise: spdy_plan_set_fused(1) (or 0) pins one path, and with it a field's bits, for every batch size
 // (tests/test_gpu_determinism.py).
 bool use_fused63(const spdy_plan *p, int nb) { return p->tab.trunc == 63 && p->fused_mode != 0 && (nb >= 80 || p->fused_mode == 1); }
+// The composite entry points (uvspec/grad -> grid, vdspec, the mixed batches) are one fused launch against two to four
+// four-kernel sequences: the fused kernels win there at any size.
+bool use_fused63_composite(const spdy_plan *p) { return p->tab.trunc == 63 && p->fused_mode != 0; }
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
@@ -735,7 +738,7 @@ static int derived_to_grid(spdy_plan *p, int nb, int mode, const double *in0, co
         // rows of psdy that grad leaves untouched (l > trunc+1 inside row nx) are never read by the transform
         KERNEL(spdy::launch_grad(p->dev, nb, in0, p->tmp_c, p->tmp_d, p->stream));
     }
-    if (use_fused63(p, 2 * nb)) {               // both derived spectra in ONE fused launch (two segments)
+    if (use_fused63_composite(p)) {             // both derived spectra in ONE fused launch (two segments)
         spdy::T63Batch b{};
         b.nseg = 2;
         b.seg[0] = spdy::T63Seg{p->tmp_c, g0, nullptr, nullptr, nb, kcos, 0, 0};
@@ -791,7 +794,7 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
         KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
         return SPDY_OK;
     }
-    if (use_fused63(p, 2 * nb)) {               // both scaled transforms in ONE fused launch (two segments) + vds
+    if (use_fused63_composite(p)) {             // both scaled transforms in ONE fused launch (two segments) + vds
         RC(ensure_four(p));
         spdy::T63Batch b{};
         b.nseg = 2;
@@ -823,7 +826,7 @@ int spdy_inverse_batch_dev(spdy_plan *p, int npairs, const double *vor, const do
             return spdy::launch_s2g_fused(p->dev, npairs, vor, nullptr, kcos_pairs, ug, p->num_cu * p->wg_per_cu, p->stream, 3, dv, vg,
                                           nplain, spec, d_kcos, kcos_all, grid);
         });
-    if (npairs > 0 && nplain > 0 && use_fused63(p, 2 * npairs + nplain)) {
+    if (npairs > 0 && nplain > 0 && use_fused63_composite(p)) {
         // T63: uvspec, then the U, V and plain spectra as three segments of ONE fused launch
         RC(ensure_four(p));
         KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
@@ -852,7 +855,7 @@ int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const doub
             return spdy::launch_g2s_fused(p->dev, npairs, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm, nplain, grid, spec);
         });
     }
-    if (npairs > 0 && nplain > 0 && use_fused63(p, 2 * npairs + nplain)) {
+    if (npairs > 0 && nplain > 0 && use_fused63_composite(p)) {
         // T63: the scaled u, v grids and the plain grids as three segments of ONE fused launch, then vds
         RC(ensure_four(p));
         const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;

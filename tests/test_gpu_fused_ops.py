@@ -151,7 +151,10 @@ def test_direct_batch_one_launch(res, npairs, nplain):
     sp.direct_batch_dev(ug, vg, got[0], got[1], gp, got[2], 2)
     sp.synchronize()
     for a, b in zip(got, want):
-        assert torch.equal(a, b)
+        if res == "t63":     # auto mode: the plain fields of `want` (under 80) took the four-kernel path -- equal to rounding
+            ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
+        else:
+            assert torch.equal(a, b)
     sp.close()
 
 
@@ -176,5 +179,8 @@ def test_inverse_batch_one_launch(res, npairs, nplain):
     sp.inverse_batch_dev(vor, div, got[0], got[1], spl, got[2], kcos_pairs=2, d_kcos=kc)
     sp.synchronize()
     for a, b in zip(got, want):
-        assert torch.equal(a, b)
+        if res == "t63":     # auto mode: the plain fields of `want` (under 80) took the four-kernel path -- equal to rounding
+            ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
+        else:
+            assert torch.equal(a, b)
     sp.close()
