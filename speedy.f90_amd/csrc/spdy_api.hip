@@ -842,6 +842,39 @@ int spdy_inverse_batch_dev(spdy_plan *p, int npairs, const double *vor, const do
     return SPDY_OK;
 }
 
+int spdy_inverse_batch_grad_dev(spdy_plan *p, int npairs, const double *vor, const double *dv, double *ug, double *vg, int kcos_pairs,
+                                int nplain, const double *spec, const int *d_kcos, int kcos_all, double *grid,
+                                int ngrad, const double *psi, double *gx, double *gy, int kcos_grad)
+{
+    NEED_DEVICE(p);
+    RC(check_batch(p, npairs));
+    RC(check_batch(p, nplain));
+    RC(check_batch(p, ngrad));
+    if ((npairs && (!vor || !dv || !ug || !vg)) || (nplain && (!spec || !grid)) || (ngrad && (!psi || !gx || !gy)))
+        return fail(SPDY_ERR_ARG, "null device pointer");
+    kcos_pairs = kcos_pairs == 1 ? 1 : 2;
+    kcos_grad = kcos_grad == 1 ? 1 : 2;
+    if (use_fused63_composite(p) && npairs > 0 && nplain > 0 && ngrad > 0 && npairs + ngrad <= p->max_batch) {
+        // T63: both operator kernels write into the plan's temporaries, then U, V, d/dlambda, d/dmu and the plain spectra
+        // are five segments of ONE fused launch (the gradient alone would be a one-workgroup launch of a full pipeline latency)
+        RC(ensure_four(p));
+        const size_t off = (size_t)npairs * spec_elems(p);
+        KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
+        KERNEL(spdy::launch_grad(p->dev, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
+        spdy::T63Batch b{};
+        b.nseg = 5;
+        b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        b.seg[1] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        b.seg[2] = spdy::T63Seg{spec, grid, nullptr, d_kcos, nplain, kcos_all, 0, 0};
+        b.seg[3] = spdy::T63Seg{p->tmp_c + off, gx, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
+        b.seg[4] = spdy::T63Seg{p->tmp_d + off, gy, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
+        return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
+    }
+    RC(spdy_inverse_batch_dev(p, npairs, vor, dv, ug, vg, kcos_pairs, nplain, spec, d_kcos, kcos_all, grid));
+    if (ngrad) RC(spdy_grad_to_grid_dev(p, ngrad, psi, gx, gy, kcos_grad));
+    return SPDY_OK;
+}
+
 int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const double *vg, double *vorm, double *divm, int kcos,
                           int nplain, const double *grid, double *spec)
 {

@@ -78,9 +78,9 @@ hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const 
 // Fused T63 kernels: a pair of fields per tile, six latitude chunks, accumulators / B operands resident in VGPRs
 hipError_t launch_s2g_fused_t63(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid, int max_wg,
                                 hipStream_t s);
-// One fused T63 launch over up to four independent sub-batches (own arrays, own scale / kcos policy); pair0 and npairs are
+// One fused T63 launch over up to six independent sub-batches (own arrays, own scale / kcos policy); pair0 and npairs are
 // filled in by the launcher
-constexpr int T63_MAX_SEG = 4;
+constexpr int T63_MAX_SEG = 6;
 struct T63Seg {
     const double *src;
     double *dst;

@@ -355,6 +355,14 @@ class Spectral:
                                               spec.shape[0], self._dp(spec), self._dp(d_kcos) if d_kcos is not None else None, int(kcos),
                                               self._dp(grid)))
 
+    def inverse_batch_grad_dev(self, vor, div, ug, vg, spec, grid, psi, gx, gy, kcos_pairs=2, kcos=1, d_kcos=None, kcos_grad=2):
+        """inverse_batch_dev + grad_to_grid_dev(psi -> gx, gy): everything a step transforms to the grid, one fused launch at T63."""
+        self._sync_stream()
+        check(self.lib.spdy_inverse_batch_grad_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(ug), self._dp(vg),
+                                                   int(kcos_pairs), spec.shape[0], self._dp(spec),
+                                                   self._dp(d_kcos) if d_kcos is not None else None, int(kcos), self._dp(grid),
+                                                   psi.shape[0], self._dp(psi), self._dp(gx), self._dp(gy), int(kcos_grad)))
+
     def direct_batch_dev(self, ug, vg, vor, div, grid, spec, kcos=2):
         """vdspec of the (ug, vg) pairs and grid_to_spec of `grid` in one launch (a model step's direct batch)."""
         self._sync_stream()

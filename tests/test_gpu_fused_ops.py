@@ -184,3 +184,30 @@ def test_inverse_batch_one_launch(res, npairs, nplain):
         else:
             assert torch.equal(a, b)
     sp.close()
+
+
+@pytest.mark.parametrize("res,npairs,nplain,ngrad", [("t30", 8, 32, 1), ("t63", 3, 5, 1), ("t63f", 16, 64, 1), ("t63f", 3, 4, 3)])
+def test_inverse_batch_with_gradient(res, npairs, nplain, ngrad):
+    """spdy_inverse_batch_grad_dev = spdy_inverse_batch_dev + spdy_grad_to_grid_dev (tendencies.f90:89-107, 121-123); at T63
+    the five groups of spectra are one fused launch."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral(res[:3], kx=8, max_batch=max(npairs + ngrad, nplain, 8), device=0)
+    if res.endswith("f"):
+        sp.set_fused(1)
+    S = torch.from_numpy(synth.spectra(2 * npairs + nplain + ngrad, sp.trunc, first=6100, full_rows=True)).cuda()
+    vor, div, spl, psi = S[:npairs], S[npairs:2 * npairs], S[2 * npairs:2 * npairs + nplain], S[2 * npairs + nplain:]
+    gs = (sp.il, sp.ix)
+    sizes = (npairs, npairs, nplain, ngrad, ngrad)
+    want = [torch.zeros((n,) + gs, dtype=torch.float64, device="cuda") for n in sizes]
+    sp.inverse_batch_dev(vor, div, want[0], want[1], spl, want[2], kcos_pairs=2, kcos=1)
+    sp.grad_to_grid_dev(psi, want[3], want[4], 2)
+    got = [torch.full((n,) + gs, float("nan"), dtype=torch.float64, device="cuda") for n in sizes]
+    sp.inverse_batch_grad_dev(vor, div, got[0], got[1], spl, got[2], psi, got[3], got[4], kcos_pairs=2, kcos=1, kcos_grad=2)
+    sp.synchronize()
+    for a, b in zip(got, want):
+        if res == "t63":     # auto mode: small separate calls take the four-kernel path -- equal to rounding
+            ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
+        else:
+            assert torch.equal(a, b)
+    sp.close()

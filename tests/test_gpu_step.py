@@ -287,8 +287,11 @@ def test_dynamical_core_step_graph(tag, one_launch_tail, oracle_factory):
     sp.use_own_stream()
     torch.cuda.synchronize()
     with sp.graph_capture() as g:
-        sp.inverse_batch_dev(D["vor"][1], D["div"][1], ug, vg, spec_plain, plain_g, kcos_pairs=2, kcos=1)
-        sp.grad_to_grid_dev(D["ps"][1:2], px, py, 2)
+        if one_launch_tail:      # ... and everything that goes to the grid as one call (one fused launch at T63)
+            sp.inverse_batch_grad_dev(D["vor"][1], D["div"][1], ug, vg, spec_plain, plain_g, D["ps"][1:2], px, py, kcos_pairs=2, kcos=1)
+        else:
+            sp.inverse_batch_dev(D["vor"][1], D["div"][1], ug, vg, spec_plain, plain_g, kcos_pairs=2, kcos=1)
+            sp.grad_to_grid_dev(D["ps"][1:2], px, py, 2)
         sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
         sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
         if one_launch_tail:      # the five spectral-space kernels below as ONE launch (spdy_spectral_step_dev)
