@@ -256,9 +256,9 @@ int spdy_direct_batch_dev(spdy_plan *plan, int npairs, const double *d_ug, const
                           double *d_divm, int kcos, int nplain, const double *d_grid, double *d_spec);
 /* spdy_inverse_batch_dev followed by spdy_grad_to_grid_dev(ngrad, d_psi, d_gx, d_gy, kcos_grad) -- everything
  * get_grid_point_tendencies transforms to the grid before its level loops (tendencies.f90:89-107 and the grad(ps) /
- * spec_to_grid(.,2) pair of :121-123).  At T63 the five groups of spectra are one fused launch (a lone gradient is a
- * one-workgroup launch of a full pipeline latency); at T30 it is the two calls.  npairs + ngrad <= max_batch for the
- * one-launch form.                                                                                                  */
+ * spec_to_grid(.,2) pair of :121-123).  One launch at T30 (gradient tiles ride along in the mixed kernel); at T63 the
+ * five groups of spectra are one fused launch behind the two operator kernels (a lone gradient is a one-workgroup
+ * launch of a full pipeline latency).  npairs + ngrad <= max_batch for the one-launch T63 form.                                                                                                */
 int spdy_inverse_batch_grad_dev(spdy_plan *plan, int npairs, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
                                 int kcos_pairs, int nplain, const double *d_spec, const int *d_kcos, int kcos_all, double *d_grid,
                                 int ngrad, const double *d_psi, double *d_gx, double *d_gy, int kcos_grad);

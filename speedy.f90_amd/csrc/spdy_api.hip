@@ -212,6 +212,15 @@ int upload_all(spdy_plan *p)
     UP(t.el2, el2); UP(t.elm2, elm2); UP(t.trfilt, trfilt); UP(t.gradx, gradx); UP(t.gradym, gradym);
     UP(t.gradyp, gradyp); UP(t.uvdx, uvdx); UP(t.uvdym, uvdym); UP(t.uvdyp, uvdyp); UP(t.vddym, vddym);
     UP(t.vddyp, vddyp);
+    {   // gradient tiles of the mixed inverse kernel: gradx indexed like the [nx][mx] tables, and one all-zero spectrum
+        std::vector<double> gxe((size_t)t.mx * t.nx), zero((size_t)2 * t.mx * t.nx, 0.0);
+        for (int n = 0; n < t.nx; ++n)
+            for (int m = 0; m < t.mx; ++m) gxe[(size_t)n * t.mx + m] = t.gradx[m];
+        UP(gxe, gradx_e);
+        const double *z = nullptr;
+        if ((rc = dev_upload(p, zero, &z))) return rc;
+        p->d_zero_spec = z;
+    }
 #undef UP
     // FFT constants: FFTPACK `work` split by stage (fftpack.f90:45-66 layout)
     spdy::FftConstants fc;
@@ -854,6 +863,11 @@ int spdy_inverse_batch_grad_dev(spdy_plan *p, int npairs, const double *vor, con
         return fail(SPDY_ERR_ARG, "null device pointer");
     kcos_pairs = kcos_pairs == 1 ? 1 : 2;
     kcos_grad = kcos_grad == 1 ? 1 : 2;
+    if (use_fused(p, npairs) && npairs > 0 && nplain > 0 && ngrad > 0)   // T30: uvspec pairs, gradients and plain fields in ONE launch
+        return timed(p, SPDY_K_S2G_FUSED, [&] {
+            return spdy::launch_s2g_fused(p->dev, npairs, vor, nullptr, kcos_pairs, ug, p->num_cu * p->wg_per_cu, p->stream, 3, dv, vg,
+                                          nplain, spec, d_kcos, kcos_all, grid, ngrad, psi, gx, gy, kcos_grad, p->d_zero_spec);
+        });
     if (use_fused63_composite(p) && npairs > 0 && nplain > 0 && ngrad > 0 && npairs + ngrad <= p->max_batch) {
         // T63: both operator kernels write into the plan's temporaries, then U, V, d/dlambda, d/dmu and the plain spectra
         // are five segments of ONE fused launch (the gradient alone would be a one-workgroup launch of a full pipeline latency)

@@ -27,6 +27,7 @@ struct DevPlan {
     const double *cosgr2;   // [il]
     // spectral operator tables, each [nx][mx] (gradx: [mx])
     const double *el2, *elm2, *trfilt, *gradx, *gradym, *gradyp, *uvdx, *uvdym, *uvdyp, *vddym, *vddyp;
+    const double *gradx_e;  // gradx expanded to [nx][mx] (gradient tiles of the mixed inverse kernel index it like uvdx)
     // implicit tables
     const double *xd, *xc, *xj, *tref1, *dhsx, *elz;
     // per-level tables [kx]: sigma-level functions (geometry.f90:51-60, geopotential.f90:22-30,53,
@@ -66,7 +67,9 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
 hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid,
                             int max_wg, hipStream_t s, int mode = 0, const double *spec2 = nullptr, double *grid2 = nullptr,
                             int nplain = 0, const double *spec_p = nullptr, const int *kcos_p = nullptr, int kcos_all_p = 1,
-                            double *grid_p = nullptr);
+                            double *grid_p = nullptr, int ngrad = 0, const double *psi = nullptr, double *gx = nullptr,
+                            double *gy = nullptr, int kcos_grad = 2, const double *zero = nullptr);
+// (mode 3, ngrad > 0: gradient tiles psi[i] -> gx[i], gy[i] ride along as uvspec tiles with vor = `zero` and the grad tables)
 // grid2 / spec2 non-null: vdspec in one pass -- tile i is the pair (grid[i], grid2[i]) scaled by gscale, the
 // outputs are vds of the pair's spectra: vorticity -> spec, divergence -> spec2 (nb pairs)
 // nplain > 0: a model step's whole direct batch in one launch -- nb (u,v) pairs as above plus nplain ordinary fields

@@ -27,6 +27,7 @@ struct spdy_plan {
     // host-pointer API staging: four buffers of max_batch grids each, allocated at the first host-pointer call
     double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;
     size_t stage_elems = 0;
+    const double *d_zero_spec = nullptr;         // one all-zero spectrum (gradient tiles of the mixed inverse kernel)
     double *tmp_c = nullptr, *tmp_d = nullptr;   // max_batch spectra each; allocated with `four` (multi-kernel operator sequences)
     double *out_grid = nullptr, *out_spec = nullptr;   // output path: (5kx+1) grids, (3kx+1) spectra (spdy_output_workspace)
     int *d_kcos = nullptr;

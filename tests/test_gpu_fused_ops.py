@@ -186,10 +186,11 @@ def test_inverse_batch_one_launch(res, npairs, nplain):
     sp.close()
 
 
-@pytest.mark.parametrize("res,npairs,nplain,ngrad", [("t30", 8, 32, 1), ("t63", 3, 5, 1), ("t63f", 16, 64, 1), ("t63f", 3, 4, 3)])
+@pytest.mark.parametrize("res,npairs,nplain,ngrad", [("t30", 8, 32, 1), ("t30", 1, 1, 1), ("t30", 5, 3, 4), ("t30", 300, 299, 7),
+                                                     ("t63", 3, 5, 1), ("t63f", 16, 64, 1), ("t63f", 3, 4, 3)])
 def test_inverse_batch_with_gradient(res, npairs, nplain, ngrad):
-    """spdy_inverse_batch_grad_dev = spdy_inverse_batch_dev + spdy_grad_to_grid_dev (tendencies.f90:89-107, 121-123); at T63
-    the five groups of spectra are one fused launch."""
+    """spdy_inverse_batch_grad_dev = spdy_inverse_batch_dev + spdy_grad_to_grid_dev (tendencies.f90:89-107, 121-123): ONE launch
+    at T30 (gradient tiles ride along as uvspec tiles with a zero vorticity and the grad tables), one five-segment fused launch at T63."""
     import torch
     import speedy_f90_amd as s
     sp = s.Spectral(res[:3], kx=8, max_batch=max(npairs + ngrad, nplain, 8), device=0)
