@@ -202,9 +202,10 @@ def test_inverse_batch_with_gradient(res, npairs, nplain, ngrad):
     sizes = (npairs, npairs, nplain, ngrad, ngrad)
     want = [torch.zeros((n,) + gs, dtype=torch.float64, device="cuda") for n in sizes]
     sp.inverse_batch_dev(vor, div, want[0], want[1], spl, want[2], kcos_pairs=2, kcos=1)
-    sp.grad_to_grid_dev(psi, want[3], want[4], 2)
+    kg = 1 if ngrad == 4 else 2                               # the gradient's own kcos, different from the pairs' once
+    sp.grad_to_grid_dev(psi, want[3], want[4], kg)
     got = [torch.full((n,) + gs, float("nan"), dtype=torch.float64, device="cuda") for n in sizes]
-    sp.inverse_batch_grad_dev(vor, div, got[0], got[1], spl, got[2], psi, got[3], got[4], kcos_pairs=2, kcos=1, kcos_grad=2)
+    sp.inverse_batch_grad_dev(vor, div, got[0], got[1], spl, got[2], psi, got[3], got[4], kcos_pairs=2, kcos=1, kcos_grad=kg)
     sp.synchronize()
     for a, b in zip(got, want):
         if res == "t63":     # auto mode: small separate calls take the four-kernel path -- equal to rounding
