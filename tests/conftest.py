@@ -41,7 +41,7 @@ def golden():
 
 # tag -> (trunc, ix, iy, kx): the stock builds and the other level counts (oracle/build_ref.sh variants)
 VARIANTS = {"t30": (30, 96, 24, 8), "t63": (63, 192, 48, 8), "t30k5": (30, 96, 24, 5), "t30k7": (30, 96, 24, 7),
-            "t63k16": (63, 192, 48, 16)}
+            "t63k16": (63, 192, 48, 16), "t30k20": (30, 96, 24, 20)}
 
 
 @pytest.fixture(scope="session")
@@ -54,7 +54,7 @@ def oracle_factory():
     def get(tag):
         if tag not in cache:
             cache[tag] = Oracle(*VARIANTS[tag])
-            if tag == "t63k16":                       # the reference has no 16-level sigma set (geometry.f90:42-48)
-                cache[tag].set_sigma(synth.SIGMA_L16)
+            if tag in synth.SIGMA_SETS:               # level counts the reference has no sigma set for (geometry.f90:42-48)
+                cache[tag].set_sigma(synth.SIGMA_SETS[tag])
         return cache[tag]
     return get

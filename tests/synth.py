@@ -63,6 +63,14 @@ SIGMA_L16 = np.array([0.000, 0.025, 0.050, 0.095, 0.140, 0.200, 0.260, 0.340, 0.
                       0.900, 0.950, 1.000], np.float32).astype(np.float64)
 
 
+# 20 half levels for the kx > 16 code paths (level rows looped inside a block; the one-launch spectral step falls back to
+# its five kernels): no reference build exists for it -- the oracle is the restatement that is pinned at 5, 7, 8 and 16 levels.
+SIGMA_L20 = np.concatenate([[0.0], np.cumsum(np.array([0.02, 0.025, 0.03, 0.04, 0.045, 0.05, 0.055, 0.06, 0.065, 0.07, 0.07, 0.07,
+                                                       0.065, 0.06, 0.055, 0.05, 0.045, 0.04, 0.035, 0.05]))]).astype(np.float32).astype(np.float64)
+SIGMA_L20[-1] = 1.0
+SIGMA_SETS = {"t63k16": SIGMA_L16, "t30k20": SIGMA_L20}
+
+
 def tail_inputs(kx, nx, mx, seed=99):
     """Seeded (divdt, tdt, psdt)-shaped complex inputs: [kx,nx,mx] x 1e-6, [kx,nx,mx] x 1e-3, [nx,mx] x 1e-5."""
     u = splitmix64(seed, 2 * (2 * kx + 1) * nx * mx).reshape(2 * kx + 1, nx, mx, 2) * 2 - 1

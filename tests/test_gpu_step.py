@@ -28,8 +28,8 @@ def make_plan(tag, max_batch):
     import speedy_f90_amd as s
     trunc, ix, iy, kx = VARIANTS[tag]
     sp = s.Spectral((trunc, ix, iy), kx=kx, max_batch=max_batch, device=0)
-    if tag == "t63k16":
-        sp.set_sigma(synth.SIGMA_L16)
+    if tag in synth.SIGMA_SETS:
+        sp.set_sigma(synth.SIGMA_SETS[tag])
     return sp
 
 
@@ -48,7 +48,7 @@ def state(sp, seed):
     return st
 
 
-@pytest.mark.parametrize("tag", ["t30", "t63", "t30k5", "t63k16"])
+@pytest.mark.parametrize("tag", ["t30", "t63", "t30k5", "t63k16", "t30k20"])
 def test_step_entry_points_vs_oracle(tag, oracle_factory):
     import torch
     sp, o = make_plan(tag, 64), oracle_factory(tag)
@@ -260,7 +260,7 @@ def oracle_dynamics_step(o, st, j1, dt, eps):
 
 
 @pytest.mark.parametrize("one_launch_tail", [False, True])
-@pytest.mark.parametrize("tag", ["t30", "t63k16"])
+@pytest.mark.parametrize("tag", ["t30", "t63k16", "t30k20"])
 def test_dynamical_core_step_graph(tag, one_launch_tail, oracle_factory):
     """SURVEY s8 f3 + f2: a COMPLETE adiabatic time step of the dynamical core on device-resident state, captured into one
     graph -- inverse batch (+ grad -> grid), grid-space dynamical tendencies (tendencies.f90:105-197), direct batch,
