@@ -78,8 +78,8 @@ enum { SPDY_K_LEGENDRE_INV = 0, SPDY_K_FOURIER_INV = 1, SPDY_K_FOURIER_DIR = 2, 
        SPDY_K_S2G_FUSED = 4, SPDY_K_G2S_FUSED = 5, SPDY_K_COUNT = 6 };
 int spdy_plan_set_profiling(spdy_plan *plan, int on);
 /* Kernel selection for the transforms: 1 = fused single-pass kernels (T30, T63), 0 = the four-kernel path (any
- * resolution), -1 (default) = fused, except T63 batches under 80 fields, which take the four-kernel path (lower
- * latency there).  The two paths agree to rounding, not bitwise: pin 1 or 0 when a field's bits must not depend on
+ * resolution), -1 (default) = fused, except T63 grid_to_spec batches under 80 fields, which take the four-kernel path
+ * (lower latency there).  The two paths agree to rounding, not bitwise: pin 1 or 0 when a field's bits must not depend on
  * the size of the batch it travels in.  Fused launches whose grid-side array is >= 16 MB stream it with
  * non-temporal loads/stores (the data passes through the caches once); smaller ones leave it cached for their
  * consumer.                                                                                        */

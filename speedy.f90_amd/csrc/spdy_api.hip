@@ -377,11 +377,12 @@ bool use_fused(const spdy_plan *p, int nb)
 }
 // T63: fused field-pair kernels for the plain transforms (spdy_fused_t63.inc); the operator-fused modes use the
 // multi-kernel sequences
-// Below ~80 fields a T63 launch is one field pair per workgroup on a fraction of the CUs and costs the pair's pipeline
-// latency (28-30 us, tools/t63_small_batch.py); the four-kernel pipeline spreads such a batch over more workgroups
-// (20-24 us), so "auto" takes it there (a T63 L16 model step: 311 -> 268 us).  The two paths agree to rounding, not
-// bitwise: spdy_plan_set_fused(1) (or 0) pins one path, and with it a field's bits, for every batch size
-// (tests/test_gpu_determinism.py).
+// T63, direct transform: below ~80 fields a launch is one field pair per workgroup on a fraction of the CUs and costs the
+// pair's pipeline latency (26-27 us, tools/t63_small_batch.py); the four-kernel pipeline spreads such a batch over more
+// workgroups (21-24 us), so "auto" takes it there.  The two paths agree to rounding, not bitwise: spdy_plan_set_fused(1)
+// (or 0) pins one path, and with it a field's bits, for every batch size (tests/test_gpu_determinism.py).
+// The inverse transform has no such threshold: its small batches run the fused kernel by (pair, chunk) items
+// (12-13 us against 20-25 us for the four-kernel pipeline).
 bool use_fused63(const spdy_plan *p, int nb) { return p->tab.trunc == 63 && p->fused_mode != 0 && (nb >= 80 || p->fused_mode == 1); }
 // The composite entry points (uvspec/grad -> grid, vdspec, the mixed batches) are one fused launch against two to four
 // four-kernel sequences: the fused kernels win there at any size.
@@ -574,7 +575,7 @@ int spdy_spec_to_grid_dev(spdy_plan *p, int nb, const double *d_spec, const int 
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu * p->wg_per_cu, p->stream);
         });
-    if (use_fused63(p, nb))
+    if (use_fused63_composite(p))               // (the inverse kernel serves every batch size: by-chunk items for small ones)
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused_t63(p->dev, nb, d_spec, d_kcos, kcos_all, d_grid, p->num_cu, p->stream);
         });

@@ -824,7 +824,8 @@ hipError_t prepare_device_kernels()
         SPDY_K2(g2s_fused_t30_kernel, 2, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 3, t30::G2S_LDS),
         SPDY_K2(g2s_fused_t63_kernel, 0, t63::LDS_BYTES), SPDY_K2(g2s_fused_t63_kernel, 1, t63::LDS_BYTES),
 #undef SPDY_K2
-        {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(s2g_fused_t63_kernel<true>), t63::LDS_BYTES},
+        {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, false>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(s2g_fused_t63_kernel<true, false>), t63::LDS_BYTES},
+        {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, true>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {
         hipError_t e = hipFuncSetAttribute(b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.bytes);

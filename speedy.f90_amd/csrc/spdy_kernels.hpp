@@ -93,6 +93,7 @@ struct T63Seg {
 };
 struct T63Batch {
     int nseg, npairs;
+    int by_chunk, pad;     // inverse, small batches: work items are (pair, chunk) instead of whole pairs (set by the launcher)
     T63Seg seg[T63_MAX_SEG];
 };
 hipError_t launch_s2g_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
