@@ -70,11 +70,20 @@ __global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *_
 
 static size_t implicit_lds(int kx) { return (size_t)3 * kx * 64 * 16; }
 
+size_t spectral_step_lds(int kx);
+__global__ void spectral_step_kernel(DevPlan p, SpecStep a);
+
 hipError_t prepare_device_step_kernels(int kx)
 {
-    if (implicit_lds(kx) <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(implicit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)implicit_lds(kx));
+    if (implicit_lds(kx) > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(implicit_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)implicit_lds(kx));
+        if (e != hipSuccess) return e;
+    }
+    if (kx <= 16 && spectral_step_lds(kx) > 64 * 1024)
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(spectral_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)spectral_step_lds(kx));
+    return hipSuccess;
 }
 
 hipError_t launch_implicit(const DevPlan &p, double *divdt, double *tdt, double *psdt, hipStream_t s)
@@ -353,7 +362,7 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // ------------------------------------------------------------------------------------------
 __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];           // [4][kx][64] complex: divdt, tdt, yf / d, scratch
+    extern __shared__ __attribute__((aligned(16))) double sm[];           // complex planes [kx][64]: divdt, tdt, phi / yf / d, div, t; + rows
     const int kx = p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
     const int e = blockIdx.x * 64 + tx;
     const bool valid = e < sz;
@@ -368,43 +377,67 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     cpx divdt = ld(a.pdiv, i) - p.el2[ec] * (-ld(a.pspec, i));
     cpx tdt = ld(a.pdiv, (long)kx * sz + i) + ld(a.pspec, (long)kx * sz + i);
     cpx trdt = ld(a.pdiv, (long)2 * kx * sz + i) + ld(a.pspec, (long)2 * kx * sz + i);
-    put(sdiv, k, divdt);
-    put(stdt, k, tdt);
+    // ---- get_spectral_tendencies (time level 1 of div, t, ps).  Every thread brings its own level of div and t into LDS (one
+    // coalesced global round trip for the block); the three level recurrences -- vertical mean, sigma-dot prefix sum, the
+    // hydrostatic integration -- are then short loops over LDS by ONE wave each (k = 0 and k = 1 run them side by side),
+    // and everything else (tdt, divdt updates, phi write-out) is per (coefficient, level) again.  As one thread per
+    // coefficient reading global memory level by level this phase was 40 us at T63 L16.
+    double *sdv = sm + (size_t)kx * 384, *st1 = sm + (size_t)kx * 512, *ssig = sm + (size_t)kx * 640;   // ssig: kx + 1 rows
+    double *smisc = ssig + (size_t)(kx + 1) * 128;                                                       // rows: dmean, psdt
+    put(sdv, k, ld(a.div, i));
+    put(st1, k, ld(a.t, i));
     __syncthreads();
-    // ---- get_spectral_tendencies: one thread per coefficient walks the levels (time level 1 of div, t, ps)
     cpx psdt = {0.0, 0.0};
-    if (k == 0) {
+    if (k == 0) {                                               // vertical mean, surface-pressure tendency, sigma-dot (:256-275)
         psdt = ld(a.pspec, (long)3 * kx * sz + ec);
         if (ec == 0) psdt = {0.0, 0.0};                                    // tendencies.f90:126
         cpx dmean = {0.0, 0.0};
-        for (int kk = 0; kk < kx; ++kk) dmean = dmean + p.dhs[kk] * ld(a.div, (long)kk * sz + ec);
+        for (int kk = 0; kk < kx; ++kk) dmean = dmean + p.dhs[kk] * get(sdv, kk);
         psdt = psdt - dmean;
         if (ec == 0) psdt = {0.0, 0.0};
-        cpx sig = {0.0, 0.0}, dumk = {0.0, 0.0};
+        put(smisc, 0, dmean);
+        cpx sig = {0.0, 0.0};
+        put(ssig, 0, sig);
         for (int kk = 0; kk < kx; ++kk) {
-            cpx sig1 = {0.0, 0.0}, dumk1 = {0.0, 0.0};
-            if (kk < kx - 1) {
-                sig1 = sig - p.dhs[kk] * (ld(a.div, (long)kk * sz + ec) - dmean);
-                dumk1 = (p.tref[kk + 1] - p.tref[kk]) * sig1;
-            }
-            put(stdt, kk, ((get(stdt, kk) - p.dhsr[kk] * (dumk1 + dumk)) + p.tref3[kk] * (sig1 + sig)) - p.tref2[kk] * dmean);
+            cpx sig1 = {0.0, 0.0};
+            if (kk < kx - 1) sig1 = sig - p.dhs[kk] * (get(sdv, kk) - dmean);
+            put(ssig, kk + 1, sig1);
             sig = sig1;
-            dumk = dumk1;
-        }
-        if (valid) geopotential_column(p, ec, sz, m == 0, a.t, ld(a.phis, ec), a.phi);
-        const cpx psv = ld(a.ps, ec);
-        const double l2 = p.el2[ec];
-        for (int kk = 0; kk < kx; ++kk) {
-            // (phi is re-read from global by the thread that just wrote it)
-            const cpx x = (valid ? ld(a.phi, (long)kk * sz + ec) : cpx{0.0, 0.0}) + p.rgtref[kk] * psv;
-            put(sdiv, kk, get(sdiv, kk) - l2 * (-x));
         }
     }
+    if (k == (kx > 1 ? 1 : 0)) {                                // get_geopotential (geopotential.f90:33-57) into the sy plane
+        const bool zonal = m == 0;
+        cpx tk1 = get(st1, kx - 1);
+        cpx ph = ld(a.phis, ec) + p.xgeop1[kx - 1] * tk1;
+        put(sy, kx - 1, ph);
+        for (int kk = kx - 2; kk >= 0; --kk) {
+            const cpx tk = get(st1, kk);
+            ph = (ph + p.xgeop2[kk + 1] * tk1) + p.xgeop1[kk] * tk;
+            cpx out = ph;
+            if (zonal && kk >= 1) out = ph + p.corf[kk] * (tk1 - get(st1, kk - 1));
+            put(sy, kk, out);
+            tk1 = tk;
+        }
+    }
+    __syncthreads();
+    {   // this thread's level: temperature and divergence tendencies (:277-292), phi out
+        const cpx dmean = get(smisc, 0), sig = get(ssig, k), sig1 = get(ssig, k + 1);
+        const cpx dumk = k > 0 ? (p.tref[k] - p.tref[k - 1]) * sig : cpx{0.0, 0.0};
+        const cpx dumk1 = k < kx - 1 ? (p.tref[k + 1] - p.tref[k]) * sig1 : cpx{0.0, 0.0};
+        tdt = ((tdt - p.dhsr[k] * (dumk1 + dumk)) + p.tref3[k] * (sig1 + sig)) - p.tref2[k] * dmean;
+        const cpx ph = get(sy, k);
+        if (valid) st(a.phi, i, ph);
+        const cpx x = (valid ? ph : cpx{0.0, 0.0}) + p.rgtref[k] * ld(a.ps, ec);
+        divdt = divdt - p.el2[ec] * (-x);
+    }
+    __syncthreads();                                            // (sy is reused by the implicit solve below)
+    put(sdiv, k, divdt);
+    put(stdt, k, tdt);
     __syncthreads();
     // ---- implicit_terms
     const double ez = p.elz[ec];
     {   // psdt lives with thread k == 0: broadcast through LDS scratch slot 0 of sy's fourth plane
-        double *sps = sm + (size_t)kx * 384;
+        double *sps = smisc + 128;
         if (k == 0) { sps[2 * tx] = psdt.re; sps[2 * tx + 1] = psdt.im; }
         __syncthreads();
         const cpx ps0 = {sps[2 * tx], sps[2 * tx + 1]};
@@ -474,11 +507,13 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     if (k == 0) stepf(a.ps, ec, sz, psdt, a.pspec, (long)3 * kx * sz + ec);
 }
 
+size_t spectral_step_lds(int kx) { return ((size_t)(6 * kx + 3) * 128) * sizeof(double); }   // 5 planes + (kx+1) sigma rows + 2
+
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s)
 {
     const int sz = p.mx * p.nx;
     if (p.kx > 16) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)3 * p.kx * 64 + 64) * 16;
+    const size_t lds = spectral_step_lds(p.kx);
     hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
     return hipGetLastError();
 }
