@@ -255,6 +255,14 @@ int upload_all(spdy_plan *p)
         if ((rc = dev_alloc(p, e.n * sizeof(double), &ptr))) return rc;
         *e.dst = static_cast<double *>(ptr);
     }
+    {
+        const int kxp = (kx + 1) & ~1;
+        const size_t nl = (size_t)(t.mx + t.nx + 1);
+        if ((rc = dev_alloc(p, (size_t)kx * kxp * (2 + nl) * sizeof(double), &ptr))) return rc;
+        p->d_xt = static_cast<double *>(ptr);
+        d.kxp = kxp;
+        d.xdt = p->d_xt; d.xct = p->d_xt + (size_t)kx * kxp; d.xjt = p->d_xt + (size_t)2 * kx * kxp;
+    }
     for (int i = 0; i < 6; ++i) d.dmp_t[i] = p->d_dmp[i];
     d.xd = p->d_xd; d.xc = p->d_xc; d.xj = p->d_xj; d.tref1 = p->d_tref1; d.dhsx = p->d_dhsx; d.elz = p->d_elz;
     const double *lt = p->d_levtab;

@@ -104,6 +104,18 @@ int spdy_implicit_init(spdy_plan *p, double dt)
     struct { double *dst; const std::vector<double> *src; } up[6] = {
         {p->d_xd, &t.xd}, {p->d_xc, &t.xc}, {p->d_xj, &t.xj}, {p->d_tref1, &t.tref1}, {p->d_dhsx, &t.dhsx}, {p->d_elz, &t.elz}};
     for (auto &u : up) HIP_TRY(hipMemcpy(u.dst, u.src->data(), u.src->size() * sizeof(double), hipMemcpyHostToDevice));
+    {   // row-major, row-padded copies: element (k, k1) of a column-major kx x kx matrix at [k][k1]
+        const int kx = t.kx, kxp = (kx + 1) & ~1, nl = t.mx + t.nx + 1;
+        std::vector<double> xt((size_t)kx * kxp * (2 + nl), 0.0);
+        auto tr = [&](const double *src, double *dst) {
+            for (int k = 0; k < kx; ++k)
+                for (int k1 = 0; k1 < kx; ++k1) dst[(size_t)k * kxp + k1] = src[k + (size_t)kx * k1];
+        };
+        tr(t.xd.data(), xt.data());
+        tr(t.xc.data(), xt.data() + (size_t)kx * kxp);
+        for (int l = 0; l < nl; ++l) tr(t.xj.data() + (size_t)kx * kx * l, xt.data() + (size_t)kx * kxp * (2 + l));
+        HIP_TRY(hipMemcpy(p->d_xt, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return upload_level_tables(p);
 }
 

@@ -30,6 +30,10 @@ struct DevPlan {
     const double *gradx_e;  // gradx expanded to [nx][mx] (gradient tiles of the mixed inverse kernel index it like uvdx)
     // implicit tables
     const double *xd, *xc, *xj, *tref1, *dhsx, *elz;
+    // the same matrices row-major with rows padded to kxp = kx rounded up to even (16-byte rows): xdt, xct [kx][kxp],
+    // xjt [mx+nx+1][kx][kxp] -- a thread's mat-vec row is one contiguous run instead of kx strided elements
+    const double *xdt, *xct, *xjt;
+    int kxp;
     // per-level tables [kx]: sigma-level functions (geometry.f90:51-60, geopotential.f90:22-30,53,
     // horizontal_diffusion.f90:70-82) and the reference temperature profile (implicit.f90:62-67);
     // rgtref = rgas*tref.  tref* are filled by spdy_implicit_init, the others whenever sigma levels exist.

@@ -34,6 +34,7 @@ struct spdy_plan {
     // device copies of dt-dependent tables
     double *d_dmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_xd = nullptr, *d_xc = nullptr, *d_xj = nullptr, *d_tref1 = nullptr, *d_dhsx = nullptr, *d_elz = nullptr;
+    double *d_xt = nullptr;                      // xdt | xct | xjt (row-major, padded copies for the one-launch spectral step)
     double *d_levtab = nullptr;       // [LEVTAB_COUNT][kx] per-level tables (DevPlan::dhs ... qcorv)
     int num_cu = 256;
     int wg_per_cu = 1;                // fused kernels: one 448-thread wave-specialised workgroup per CU

@@ -441,16 +441,29 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
         if (k == 0) { sps[2 * tx] = psdt.re; sps[2 * tx + 1] = psdt.im; }
         __syncthreads();
         const cpx ps0 = {sps[2 * tx], sps[2 * tx + 1]};
-        cpx ye = {0.0, 0.0};
-        for (int k1 = 0; k1 < kx; ++k1) ye = ye + p.xd[k + kx * k1] * get(stdt, k1);
+        // mat-vec rows: this thread's row of xd / xc / xj(:,:,l) is one contiguous, 16-byte aligned run of the row-major
+        // copies (xdt, xct, xjt): kxp/2 16-byte loads per row, issued four at a time, instead of kx strided 8-byte loads
+        // each waited for in turn (the level-count loops do not unroll); the sums keep the reference's order k1 = 0..kx-1
+        const int kxp = p.kxp;
+        auto matvec = [&](const double *row, double *src, cpx acc) {
+            const double2 *r2 = reinterpret_cast<const double2 *>(row);
+            for (int q = 0; q < kxp / 2; q += 4) {
+                double2 a[4];
+                UNROLL for (int j = 0; j < 4; ++j) a[j] = r2[min(q + j, kxp / 2 - 1)];
+                UNROLL for (int j = 0; j < 4; ++j) {
+                    const int k1 = 2 * (q + j);
+                    if (k1 < kx) acc = acc + a[j].x * get(src, k1);
+                    if (k1 + 1 < kx) acc = acc + a[j].y * get(src, k1 + 1);
+                }
+            }
+            return acc;
+        };
+        cpx ye = matvec(p.xdt + (size_t)k * kxp, stdt, cpx{0.0, 0.0});
         ye = ye + p.tref1[k] * ps0;
         put(sy, k, get(sdiv, k) + ez * ye);                                // yf
         __syncthreads();
         cpx d = {0.0, 0.0};
-        if (l != 0) {
-            const double *xj = p.xj + (long)kx * kx * (l - 1);
-            for (int k1 = 0; k1 < kx; ++k1) d = d + xj[k + kx * k1] * get(sy, k1);
-        }
+        if (l != 0) d = matvec(p.xjt + ((size_t)(l - 1) * kx + k) * kxp, sy, d);
         __syncthreads();
         put(sy, k, d);                                                     // divdt after the solve
         __syncthreads();
@@ -459,9 +472,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
             for (int kk = 0; kk < kx; ++kk) ps = ps - p.dhsx[kk] * get(sy, kk);
             psdt = ps;
         }
-        cpx t = get(stdt, k);
-        for (int k1 = 0; k1 < kx; ++k1) t = t + p.xc[k + kx * k1] * get(sy, k1);
-        tdt = t;
+        tdt = matvec(p.xct + (size_t)k * kxp, sy, get(stdt, k));
         divdt = d;
     }
     if (!valid) return;
