@@ -12,6 +12,16 @@
 
 #include <algorithm>
 
+#ifdef SPDY_PHASE_TRACE
+__device__ long long g_step_trace[2 * 16];   // [wave 0 / wave 1][mark] s_memtime of block 0 (debug build only; tools/step_trace.py)
+extern "C" __attribute__((visibility("default"))) int spdy_debug_step_trace(long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(g_step_trace));
+}
+#define STEP_MARK(m_) do { if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y < 2) g_step_trace[threadIdx.y * 16 + (m_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEP_MARK(m_) do { } while (0)
+#endif
 namespace spdy {
 
 // ------------------------------------------------------------------------------------------
@@ -372,6 +382,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     auto at = [&](double *b, int kk) { return b + ((size_t)kk * 64 + tx) * 2; };
     auto get = [&](double *b, int kk) { return cpx{at(b, kk)[0], at(b, kk)[1]}; };
     auto put = [&](double *b, int kk, cpx z) { at(b, kk)[0] = z.re; at(b, kk)[1] = z.im; };
+    STEP_MARK(0);
     // ---- tendency combination on the direct batch's outputs
     cpx vordt = ld(a.pvor, i);
     cpx divdt = ld(a.pdiv, i) - p.el2[ec] * (-ld(a.pspec, i));
@@ -386,7 +397,9 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     double *smisc = ssig + (size_t)(kx + 1) * 128;                                                       // rows: dmean, psdt
     put(sdv, k, ld(a.div, i));
     put(st1, k, ld(a.t, i));
+    STEP_MARK(1);
     __syncthreads();
+    STEP_MARK(2);
     cpx psdt = {0.0, 0.0};
     if (k == 0) {                                               // vertical mean, surface-pressure tendency, sigma-dot (:256-275)
         psdt = ld(a.pspec, (long)3 * kx * sz + ec);
@@ -420,6 +433,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
         }
     }
     __syncthreads();
+    STEP_MARK(3);
     {   // this thread's level: temperature and divergence tendencies (:277-292), phi out
         const cpx dmean = get(smisc, 0), sig = get(ssig, k), sig1 = get(ssig, k + 1);
         const cpx dumk = k > 0 ? (p.tref[k] - p.tref[k - 1]) * sig : cpx{0.0, 0.0};
@@ -434,6 +448,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     put(sdiv, k, divdt);
     put(stdt, k, tdt);
     __syncthreads();
+    STEP_MARK(4);
     // ---- implicit_terms
     const double ez = p.elz[ec];
     {   // psdt lives with thread k == 0: broadcast through LDS scratch slot 0 of sy's fourth plane
@@ -475,6 +490,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
         tdt = matvec(p.xct + (size_t)k * kxp, sy, get(stdt, k));
         divdt = d;
     }
+    STEP_MARK(5);
     if (!valid) return;
     // ---- diffusion block of step() (time level 1 of the prognostics)
     {
@@ -495,6 +511,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
         const cpx cq = ld(a.tr, i) + p.qcorv[k] * ld(a.qcorh, ec);
         trdt = hd(cq, trdt, dmpd, dmp1d);
     }
+    STEP_MARK(6);
     // ---- step_field_3d for vor, div, t, tr and step_field_2d for ps; tendencies written back truncated, as the
     // separate kernels leave them
     const double trf = p.trfilt[ec];
@@ -516,6 +533,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     stepf(a.t, i, lvl2, tdt, a.pdiv, (long)kx * sz + i);
     stepf(a.tr, i, lvl2, trdt, a.pdiv, (long)2 * kx * sz + i);
     if (k == 0) stepf(a.ps, ec, sz, psdt, a.pspec, (long)3 * kx * sz + ec);
+    STEP_MARK(7);
 }
 
 size_t spectral_step_lds(int kx) { return ((size_t)(6 * kx + 3) * 128) * sizeof(double); }   // 5 planes + (kx+1) sigma rows + 2
