@@ -81,10 +81,17 @@ __global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *_
 static size_t implicit_lds(int kx) { return (size_t)3 * kx * 64 * 16; }
 
 size_t spectral_step_lds(int kx);
+size_t grid_tendencies_lds(int kx);
+__global__ void grid_tendencies_kernel(DevPlan p, GridTend g);
 __global__ void spectral_step_kernel(DevPlan p, SpecStep a);
 
 hipError_t prepare_device_step_kernels(int kx)
 {
+    if (kx <= 16 && grid_tendencies_lds(kx) > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_tendencies_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)grid_tendencies_lds(kx));
+        if (e != hipSuccess) return e;
+    }
     if (implicit_lds(kx) > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(implicit_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)implicit_lds(kx));
@@ -276,7 +283,8 @@ hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const
 //   plain [3 kx + 1] : 0.5*(ug^2 + vg^2) | ttend | trtend | -umean*px - vmean*py
 // (the host adds its physical tendencies to utend, vtend, ttend, trtend in between, tendencies.f90:203-206).
 // ------------------------------------------------------------------------------------------
-__global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
+// kx > 16 (more level rows than a block holds): one lane per grid point, the level recurrences stream through registers
+__global__ void grid_tendencies_serial_kernel(DevPlan p, GridTend g)
 {
     const int gsz = p.ix * p.il, kx = p.kx, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= gsz) return;
@@ -333,10 +341,94 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
 #undef LV
 }
 
+// Block = 64 grid points x kx level rows (one wave per level): every thread fetches its own level of the six fields at once
+// (one coalesced memory round trip for the block instead of one per level of a serial per-point loop: 24 -> see DESIGN at
+// T63 L16); the vertical means and the sigma-dot prefix sums are short loops over LDS by wave 0, everything else is per
+// (point, level) with the neighbouring levels read from LDS.  Expressions as in the reference's loops.
+__global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int gsz = p.ix * p.il, kx = p.kx, tx = threadIdx.x, k = threadIdx.y;
+    const int i0 = blockIdx.x * 64 + tx;
+    const bool valid = i0 < gsz;
+    const int i = valid ? i0 : gsz - 1, j = i / p.ix;
+    double *su = sm, *sv = sm + kx * 64, *st = sm + 2 * kx * 64, *sq = sm + 3 * kx * 64, *sp = sm + 4 * kx * 64, *sd = sm + 5 * kx * 64;
+    double *ssig = sm + 6 * kx * 64, *ssigm = ssig + (kx + 1) * 64, *smean = ssigm + (kx + 1) * 64;   // smean: umean, vmean, dmean rows
+    double *stab = smean + 3 * 64;                                                                    // dhs[kx]
+#define LV(a_, k_) (a_)[(long)(k_) * gsz + i]
+#define S(b_, k_) (b_)[(k_) * 64 + tx]
+    const double ug_c = LV(g.ug, k), vg_c = LV(g.vg, k), tg_c = LV(g.tg, k), tr_c = LV(g.trg, k), dv = LV(g.divg, k);
+    const double vor = LV(g.vorg, k) + p.coriol[j];                                        // (:103-107 coriolis)
+    const double px = g.px[i], py = g.py[i], rgas = p.rgas, akap = p.akap;
+    const double dhr = p.dhsr[k], trefk = p.tref[k];
+    const double tgg = tg_c - trefk;                                                       // (:149)
+    if (tx == 0) stab[k] = p.dhs[k];
+    S(su, k) = ug_c; S(sv, k) = vg_c; S(st, k) = tgg; S(sq, k) = tr_c; S(sd, k) = dv;
+    __syncthreads();
+    if (k == 0) {                                                                          // vertical means (:109-117)
+        double umean = 0.0, vmean = 0.0, dmean = 0.0;
+        for (int kk = 0; kk < kx; ++kk) {
+            const double dh = stab[kk];
+            umean = umean + S(su, kk) * dh;
+            vmean = vmean + S(sv, kk) * dh;
+            dmean = dmean + S(sd, kk) * dh;
+        }
+        smean[tx] = umean; smean[64 + tx] = vmean; smean[128 + tx] = dmean;
+    }
+    __syncthreads();
+    const double umean = smean[tx], vmean = smean[64 + tx], dmean = smean[128 + tx];
+    const double puv = (ug_c - umean) * px + (vg_c - vmean) * py;                          // (:136)
+    S(sp, k) = puv;
+    __syncthreads();
+    if (k == 0) {                                                                          // sigdt, sigm at the half levels (:139-142)
+        double sig = 0.0, sigm = 0.0;
+        S(ssig, 0) = 0.0; S(ssigm, 0) = 0.0;
+        for (int kk = 0; kk < kx; ++kk) {
+            const double dh = stab[kk], pk = S(sp, kk);
+            sig = sig - dh * (pk + S(sd, kk) - dmean);
+            sigm = sigm - dh * pk;
+            S(ssig, kk + 1) = sig; S(ssigm, kk + 1) = sigm;
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+    if (k == 0) g.plain[(long)(3 * kx) * gsz + i] = (-umean) * px - vmean * py;            // (:125)
+    const double sig = S(ssig, k), sig1 = S(ssig, k + 1), sigm = S(ssigm, k), sigm1 = S(ssigm, k + 1);
+    // fluxes temp(k) and temp(k+1) of the advected quantities (zero at the top level 1 and at kx+1: :152-153)
+    double tu = 0.0, tv = 0.0, tt = 0.0, tq = 0.0, tu1 = 0.0, tv1 = 0.0, tt1 = 0.0, tq1 = 0.0;
+    if (k > 0) {
+        tu = sig * (ug_c - S(su, k - 1));                                                  // (:156)
+        tv = sig * (vg_c - S(sv, k - 1));                                                  // (:166)
+        tt = sig * (tgg - S(st, k - 1)) + sigm * (trefk - p.tref[k - 1]);                  // (:176-177)
+        tq = sig * (tr_c - S(sq, k - 1));                                                  // (:188)
+        if (k == 1 || k == 2) tq = 0.0;                                                    // temp(:,:,2:3) = 0 (:191)
+    }
+    if (k + 1 < kx) {
+        tu1 = sig1 * (S(su, k + 1) - ug_c);
+        tv1 = sig1 * (S(sv, k + 1) - vg_c);
+        tt1 = sig1 * (S(st, k + 1) - tgg) + sigm1 * (p.tref[k + 1] - trefk);
+        tq1 = sig1 * (S(sq, k + 1) - tr_c);
+        if (k + 1 == 1 || k + 1 == 2) tq1 = 0.0;
+    }
+    LV(g.u, k) = vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr;                          // utend (:160-161)
+    LV(g.v, k) = -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr;                         // vtend (:170-171)
+    LV(g.plain, kx + k) = tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
+                          + akap * (tg_c * puv - tgg * dmean);                             // ttend (:181-184)
+    LV(g.plain, 2 * kx + k) = tr_c * dv - (tq1 + tq) * dhr;                                // trtend (:194)
+    LV(g.plain, k) = 0.5 * (ug_c * ug_c + vg_c * vg_c);                                    // kinetic energy (:220)
+    LV(g.u, kx + k) = -ug_c * tgg;  LV(g.v, kx + k) = -vg_c * tgg;                         // (:224)
+    LV(g.u, 2 * kx + k) = -ug_c * tr_c;  LV(g.v, 2 * kx + k) = -vg_c * tr_c;               // (:229)
+#undef LV
+#undef S
+}
+
+size_t grid_tendencies_lds(int kx) { return ((size_t)(6 * kx + 2 * (kx + 1) + 3) * 64 + kx) * sizeof(double); }
+
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s)
 {
     const int gsz = p.ix * p.il;
-    hipLaunchKernelGGL(grid_tendencies_kernel, dim3((gsz + 63) / 64), dim3(64), 0, s, p, g);
+    if (p.kx > 16) hipLaunchKernelGGL(grid_tendencies_serial_kernel, dim3((gsz + 63) / 64), dim3(64), 0, s, p, g);
+    else hipLaunchKernelGGL(grid_tendencies_kernel, dim3((gsz + 63) / 64), dim3(64, p.kx), grid_tendencies_lds(p.kx), s, p, g);
     return hipGetLastError();
 }
 
