@@ -24,6 +24,10 @@ extern "C" __attribute__((visibility("default"))) int spdy_debug_step_trace(long
 #endif
 namespace spdy {
 
+// Workgroup barrier that publishes LDS only: __syncthreads() also drains vmcnt, i.e. it waits for every global load in flight
+// -- the kernels below exchange data through LDS alone and keep prefetches in flight across their barriers.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------------------------------
 // implicit_terms (implicit.f90:168-217).  Block = 64 coefficients x KY level rows (one wave per row, so the
 // kx x kx matrices xd, xc are wave-uniform scalar loads; xj depends on l = m'+n per lane).  The three
@@ -84,6 +88,7 @@ size_t spectral_step_lds(int kx);
 size_t grid_tendencies_lds(int kx);
 __global__ void grid_tendencies_kernel(DevPlan p, GridTend g);
 __global__ void spectral_step_kernel(DevPlan p, SpecStep a);
+__global__ void spectral_step_kernel16(DevPlan p, SpecStep a);
 
 hipError_t prepare_device_step_kernels(int kx)
 {
@@ -98,8 +103,8 @@ hipError_t prepare_device_step_kernels(int kx)
         if (e != hipSuccess) return e;
     }
     if (kx <= 16 && spectral_step_lds(kx) > 64 * 1024)
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(spectral_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)spectral_step_lds(kx));
+        return hipFuncSetAttribute(kx <= 8 ? reinterpret_cast<const void *>(spectral_step_kernel) : reinterpret_cast<const void *>(spectral_step_kernel16),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)spectral_step_lds(kx));
     return hipSuccess;
 }
 
@@ -364,7 +369,7 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
     const double tgg = tg_c - trefk;                                                       // (:149)
     if (tx == 0) stab[k] = p.dhs[k];
     S(su, k) = ug_c; S(sv, k) = vg_c; S(st, k) = tgg; S(sq, k) = tr_c; S(sd, k) = dv;
-    __syncthreads();
+    lds_sync();
     if (k == 0) {                                                                          // vertical means (:109-117)
         double umean = 0.0, vmean = 0.0, dmean = 0.0;
         for (int kk = 0; kk < kx; ++kk) {
@@ -375,11 +380,11 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
         }
         smean[tx] = umean; smean[64 + tx] = vmean; smean[128 + tx] = dmean;
     }
-    __syncthreads();
+    lds_sync();
     const double umean = smean[tx], vmean = smean[64 + tx], dmean = smean[128 + tx];
     const double puv = (ug_c - umean) * px + (vg_c - vmean) * py;                          // (:136)
     S(sp, k) = puv;
-    __syncthreads();
+    lds_sync();
     if (k == 0) {                                                                          // sigdt, sigm at the half levels (:139-142)
         double sig = 0.0, sigm = 0.0;
         S(ssig, 0) = 0.0; S(ssigm, 0) = 0.0;
@@ -390,7 +395,7 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
             S(ssig, kk + 1) = sig; S(ssigm, kk + 1) = sigm;
         }
     }
-    __syncthreads();
+    lds_sync();
     if (!valid) return;
     if (k == 0) g.plain[(long)(3 * kx) * gsz + i] = (-umean) * px - vmean * py;            // (:125)
     const double sig = S(ssig, k), sig1 = S(ssig, k + 1), sigm = S(ssigm, k), sigm1 = S(ssigm, k + 1);
@@ -462,7 +467,10 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // geopotential recursion, the kx x kx mat-vecs) go through LDS.  Every expression is the one of the separate kernel, so
 // the results are bit-identical to the unfused sequence.
 // ------------------------------------------------------------------------------------------
-__global__ void spectral_step_kernel(DevPlan p, SpecStep a)
+// NJ = 16-byte pieces of a mat-vec row held in registers: 4 for up to 8 levels (512 threads, 256 VGPRs), 8 for up to 16
+// (1024 threads, 128 VGPRs)
+template <int NJ>
+__device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecStep &a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];           // complex planes [kx][64]: divdt, tdt, phi / yf / d, div, t; + rows
     const int kx = p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
@@ -489,8 +497,23 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     double *smisc = ssig + (size_t)(kx + 1) * 128;                                                       // rows: dmean, psdt
     put(sdv, k, ld(a.div, i));
     put(st1, k, ld(a.t, i));
+    // implicit-solve operands, fetched now and consumed four barriers later (lds_sync leaves them in flight): this thread's row
+    // of xj(:,:,l) into registers, its share of the xd / xc matrices (row-major copies, the same for every lane of a wave)
+    // on the way to LDS.  Fetched where they are used, the three mat-vecs were half of this kernel's time.
+    const int kxp = p.kxp;
+    double *sxd = smisc + 256, *sxc = sxd + kx * kxp;
+    double2 xjr[4];                                             // (levels 8..15 of the row: fetched at the start of the solve)
+    {
+        const double2 *r2 = reinterpret_cast<const double2 *>(p.xjt + ((size_t)max(l - 1, 0) * kx + k) * kxp);
+        UNROLL for (int j = 0; j < 4; ++j) xjr[j] = r2[min(j, kxp / 2 - 1)];
+    }
+    double cpd[2] = {0.0, 0.0}, cpc[2] = {0.0, 0.0};
+    UNROLL for (int j = 0; j < 2; ++j) {
+        const int q = k * 64 + tx + j * 64 * kx;
+        if (q < kx * kxp) { cpd[j] = p.xdt[q]; cpc[j] = p.xct[q]; }
+    }
     STEP_MARK(1);
-    __syncthreads();
+    lds_sync();
     STEP_MARK(2);
     cpx psdt = {0.0, 0.0};
     if (k == 0) {                                               // vertical mean, surface-pressure tendency, sigma-dot (:256-275)
@@ -524,7 +547,7 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
             tk1 = tk;
         }
     }
-    __syncthreads();
+    lds_sync();
     STEP_MARK(3);
     {   // this thread's level: temperature and divergence tendencies (:277-292), phi out
         const cpx dmean = get(smisc, 0), sig = get(ssig, k), sig1 = get(ssig, k + 1);
@@ -536,50 +559,58 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
         const cpx x = (valid ? ph : cpx{0.0, 0.0}) + p.rgtref[k] * ld(a.ps, ec);
         divdt = divdt - p.el2[ec] * (-x);
     }
-    __syncthreads();                                            // (sy is reused by the implicit solve below)
+    UNROLL for (int j = 0; j < 2; ++j) {
+        const int q = k * 64 + tx + j * 64 * kx;
+        if (q < kx * kxp) { sxd[q] = cpd[j]; sxc[q] = cpc[j]; }
+    }
+    lds_sync();                                            // (sy is reused by the implicit solve below)
     put(sdiv, k, divdt);
     put(stdt, k, tdt);
-    __syncthreads();
+    lds_sync();
     STEP_MARK(4);
     // ---- implicit_terms
     const double ez = p.elz[ec];
     {   // psdt lives with thread k == 0: broadcast through LDS scratch slot 0 of sy's fourth plane
         double *sps = smisc + 128;
         if (k == 0) { sps[2 * tx] = psdt.re; sps[2 * tx + 1] = psdt.im; }
-        __syncthreads();
+        lds_sync();
         const cpx ps0 = {sps[2 * tx], sps[2 * tx + 1]};
-        // mat-vec rows: this thread's row of xd / xc / xj(:,:,l) is one contiguous, 16-byte aligned run of the row-major
-        // copies (xdt, xct, xjt): kxp/2 16-byte loads per row, issued four at a time, instead of kx strided 8-byte loads
-        // each waited for in turn (the level-count loops do not unroll); the sums keep the reference's order k1 = 0..kx-1
-        const int kxp = p.kxp;
-        auto matvec = [&](const double *row, double *src, cpx acc) {
-            const double2 *r2 = reinterpret_cast<const double2 *>(row);
-            for (int q = 0; q < kxp / 2; q += 4) {
-                double2 a[4];
-                UNROLL for (int j = 0; j < 4; ++j) a[j] = r2[min(q + j, kxp / 2 - 1)];
-                UNROLL for (int j = 0; j < 4; ++j) {
-                    const int k1 = 2 * (q + j);
-                    if (k1 < kx) acc = acc + a[j].x * get(src, k1);
-                    if (k1 + 1 < kx) acc = acc + a[j].y * get(src, k1 + 1);
-                }
-            }
+        // mat-vec rows from the row-major copies; the sums keep the reference's order k1 = 0..kx-1
+        auto matvec = [&](const double *row, double *src, cpx acc) {                 // row in LDS (broadcast reads)
+            for (int k1 = 0; k1 < kx; ++k1) acc = acc + row[k1] * get(src, k1);
             return acc;
         };
-        cpx ye = matvec(p.xdt + (size_t)k * kxp, stdt, cpx{0.0, 0.0});
+        double2 xjl[4];
+        if (NJ > 4) {
+            const double2 *r2 = reinterpret_cast<const double2 *>(p.xjt + ((size_t)max(l - 1, 0) * kx + k) * kxp);
+            UNROLL for (int j = 0; j < 4; ++j) xjl[j] = r2[min(4 + j, kxp / 2 - 1)];
+        }
+        cpx ye = matvec(sxd + k * kxp, stdt, cpx{0.0, 0.0});
         ye = ye + p.tref1[k] * ps0;
         put(sy, k, get(sdiv, k) + ez * ye);                                // yf
-        __syncthreads();
+        lds_sync();
         cpx d = {0.0, 0.0};
-        if (l != 0) d = matvec(p.xjt + ((size_t)(l - 1) * kx + k) * kxp, sy, d);
-        __syncthreads();
+        if (l != 0) {
+            UNROLL for (int j = 0; j < 4; ++j) {
+                if (2 * j < kx) d = d + xjr[j].x * get(sy, 2 * j);
+                if (2 * j + 1 < kx) d = d + xjr[j].y * get(sy, 2 * j + 1);
+            }
+            if (NJ > 4) {
+                UNROLL for (int j = 4; j < 8; ++j) {
+                    if (2 * j < kx) d = d + xjl[j - 4].x * get(sy, 2 * j);
+                    if (2 * j + 1 < kx) d = d + xjl[j - 4].y * get(sy, 2 * j + 1);
+                }
+            }
+        }
+        lds_sync();
         put(sy, k, d);                                                     // divdt after the solve
-        __syncthreads();
+        lds_sync();
         if (k == 0) {
             cpx ps = ps0;
             for (int kk = 0; kk < kx; ++kk) ps = ps - p.dhsx[kk] * get(sy, kk);
             psdt = ps;
         }
-        tdt = matvec(p.xct + (size_t)k * kxp, sy, get(stdt, k));
+        tdt = matvec(sxc + k * kxp, sy, get(stdt, k));
         divdt = d;
     }
     STEP_MARK(5);
@@ -628,14 +659,21 @@ __global__ void spectral_step_kernel(DevPlan p, SpecStep a)
     STEP_MARK(7);
 }
 
-size_t spectral_step_lds(int kx) { return ((size_t)(6 * kx + 3) * 128) * sizeof(double); }   // 5 planes + (kx+1) sigma rows + 2
+__global__ __launch_bounds__(512, 2) void spectral_step_kernel(DevPlan p, SpecStep a) { spectral_step_body<4>(p, a); }
+__global__ __launch_bounds__(1024, 4) void spectral_step_kernel16(DevPlan p, SpecStep a) { spectral_step_body<8>(p, a); }
+
+size_t spectral_step_lds(int kx)   // 5 planes + (kx+1) sigma rows + 2 rows + row-major xd, xc
+{
+    return ((size_t)(6 * kx + 3) * 128 + 2 * kx * ((kx + 1) & ~1)) * sizeof(double);
+}
 
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s)
 {
     const int sz = p.mx * p.nx;
     if (p.kx > 16) return hipErrorInvalidValue;
     const size_t lds = spectral_step_lds(p.kx);
-    hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
+    if (p.kx <= 8) hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
+    else hipLaunchKernelGGL(spectral_step_kernel16, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
     return hipGetLastError();
 }
 
