@@ -184,7 +184,7 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
     g.close(); sp.close()
     # timing only (synthetic state, the plain-field gather of a real host is not part of the graph); parity of this exact
     # sequence is tests/test_gpu_step.py::test_dynamical_core_step_graph
-    return {"us_per_step": us, "launches_in_graph": 4 if res == "t30" else 7, "transforms": 6 * kx + 2 + 9 * kx + 1, "levels": kx}
+    return {"us_per_step": us, "launches_in_graph": 4 if res == "t30" else 6, "transforms": 6 * kx + 2 + 9 * kx + 1, "levels": kx}
 
 
 def extras(s, torch, synth, sp, dev, args):

@@ -878,12 +878,11 @@ int spdy_inverse_batch_grad_dev(spdy_plan *p, int npairs, const double *vor, con
                                           nplain, spec, d_kcos, kcos_all, grid, ngrad, psi, gx, gy, kcos_grad, p->d_zero_spec);
         });
     if (use_fused63_composite(p) && npairs > 0 && nplain > 0 && ngrad > 0 && npairs + ngrad <= p->max_batch) {
-        // T63: both operator kernels write into the plan's temporaries, then U, V, d/dlambda, d/dmu and the plain spectra
+        // T63: ONE operator launch (uvspec | grad) writes into the plan's temporaries, then U, V, d/dlambda, d/dmu and the plain spectra
         // are five segments of ONE fused launch (the gradient alone would be a one-workgroup launch of a full pipeline latency)
         RC(ensure_four(p));
         const size_t off = (size_t)npairs * spec_elems(p);
-        KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
-        KERNEL(spdy::launch_grad(p->dev, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
+        KERNEL(spdy::launch_uvspec_grad(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
         spdy::T63Batch b{};
         b.nseg = 5;
         b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};

@@ -729,9 +729,9 @@ __global__ void scale_op_kernel(DevPlan p, int op, long total, const double *__r
 }
 
 // grad (spectral.f90:124-144)
-__global__ void grad_kernel(DevPlan p, long total, const double *__restrict__ psi, double *__restrict__ dx, double *__restrict__ dy)
+__device__ __forceinline__ void grad_body(const DevPlan &p, long i, long total, const double *__restrict__ psi, double *__restrict__ dx,
+                                          double *__restrict__ dy)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int sz = p.mx * p.nx, e = (int)(i % sz), m = e % p.mx, n = e / p.mx;
     const long f0 = i - e;
@@ -742,6 +742,11 @@ __global__ void grad_kernel(DevPlan p, long total, const double *__restrict__ ps
     else if (n <= p.trunc) r = (-p.gradym[e]) * ld(psi, i - p.mx) + p.gradyp[e] * ld(psi, i + p.mx);
     else return;
     st(dy, i, r);
+}
+
+__global__ void grad_kernel(DevPlan p, long total, const double *__restrict__ psi, double *__restrict__ dx, double *__restrict__ dy)
+{
+    grad_body(p, (long)blockIdx.x * blockDim.x + threadIdx.x, total, psi, dx, dy);
 }
 
 // vds (spectral.f90:146-171): (U,V) -> (vor,div)
@@ -768,10 +773,9 @@ __global__ void vds_kernel(DevPlan p, long total, const double *__restrict__ u, 
 }
 
 // uvspec (spectral.f90:173-196): (vor,div) -> (U,V)
-__global__ void uvspec_kernel(DevPlan p, long total, const double *__restrict__ vor, const double *__restrict__ dv,
-                              double *__restrict__ u, double *__restrict__ v)
+__device__ __forceinline__ void uvspec_body(const DevPlan &p, long i, long total, const double *__restrict__ vor,
+                                            const double *__restrict__ dv, double *__restrict__ u, double *__restrict__ v)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int sz = p.mx * p.nx, e = (int)(i % sz), m = e % p.mx, n = e / p.mx;
     const long f0 = i - e;
@@ -788,6 +792,22 @@ __global__ void uvspec_kernel(DevPlan p, long total, const double *__restrict__ 
         st(v, i, ((-p.uvdym[e]) * ld(dv, i - p.mx) + p.uvdyp[e] * ld(dv, i + p.mx)) + zp);
         st(u, i, (p.uvdym[e] * ld(vor, i - p.mx) - p.uvdyp[e] * ld(vor, i + p.mx)) + zc);
     }
+}
+
+__global__ void uvspec_kernel(DevPlan p, long total, const double *__restrict__ vor, const double *__restrict__ dv,
+                              double *__restrict__ u, double *__restrict__ v)
+{
+    uvspec_body(p, (long)blockIdx.x * blockDim.x + threadIdx.x, total, vor, dv, u, v);
+}
+
+// uvspec of one set of fields and grad of another in ONE launch (blockIdx.y): what a step applies before its inverse batch
+__global__ void uvspec_grad_kernel(DevPlan p, long total_uv, const double *__restrict__ vor, const double *__restrict__ dv,
+                                   double *__restrict__ u, double *__restrict__ v, long total_gr, const double *__restrict__ psi,
+                                   double *__restrict__ dx, double *__restrict__ dy)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) uvspec_body(p, i, total_uv, vor, dv, u, v);
+    else grad_body(p, i, total_gr, psi, dx, dy);
 }
 
 // do_horizontal_diffusion (horizontal_diffusion.f90:86-105)
@@ -925,6 +945,17 @@ hipError_t launch_uvspec(const DevPlan &p, int nb, const double *vor, const doub
     const long total = (long)nb * p.mx * p.nx;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(uvspec_kernel, blocks_for(total), dim3(256), 0, s, p, total, vor, div, u, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_uvspec_grad(const DevPlan &p, int nuv, const double *vor, const double *div, double *u, double *v, int ngr,
+                              const double *psi, double *psdx, double *psdy, hipStream_t s)
+{
+    const long tuv = (long)nuv * p.mx * p.nx, tgr = (long)ngr * p.mx * p.nx;
+    if (tuv <= 0 || tgr <= 0) return hipErrorInvalidValue;
+    dim3 grd = blocks_for(tuv > tgr ? tuv : tgr);
+    grd.y = 2;
+    hipLaunchKernelGGL(uvspec_grad_kernel, grd, dim3(256), 0, s, p, tuv, vor, div, u, v, tgr, psi, psdx, psdy);
     return hipGetLastError();
 }
 

@@ -109,6 +109,8 @@ hipError_t launch_scale_op(const DevPlan &p, int op, int nb, const double *in, d
 hipError_t launch_grad(const DevPlan &p, int nb, const double *psi, double *psdx, double *psdy, hipStream_t s);
 hipError_t launch_vds(const DevPlan &p, int nb, const double *u, const double *v, double *vor, double *div, hipStream_t s);
 hipError_t launch_uvspec(const DevPlan &p, int nb, const double *vor, const double *div, double *u, double *v, hipStream_t s);
+hipError_t launch_uvspec_grad(const DevPlan &p, int nuv, const double *vor, const double *div, double *u, double *v, int ngr,
+                              const double *psi, double *psdx, double *psdy, hipStream_t s);
 hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const double *fdt, const double *dmp,
                         const double *dmp1, double *out, hipStream_t s);
 struct HdiffOps {   // up to 8 independent diffusion operations, passed by value as one kernel argument
