@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="fields per GPU (default 6144 at T30, 1536 at T63)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the timed steps as eager launches instead of one HIP graph replay")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time the level all-gather of the sharded implicit solve (outside the timed region)")
     ap.add_argument("--no-extras", action="store_true", help="skip the model-shaped / operator-fused / T63 side measurements")
     ap.add_argument("--fused", type=int, default=-1, help="1 fused single-pass kernels, 0 four-kernel path, -1 auto")
     args = ap.parse_args()
@@ -367,7 +368,7 @@ def main():
     # transform metric can be read "with and without the gather"
     gather_ms = None
     gather_cabi_ms = None
-    if dist and args.res == "t30":
+    if dist and args.res == "t30" and args.gather:   # opt-in: a second RCCL communicator and extra collectives are not worth a hang in the scaling run
         try:   # the same exchange through the C ABI (spdy_comm_*: one grouped RCCL call on the plan's stream)
             comm = s.sharding.LevelComm(sp)
             full = [torch.zeros((sp.kx, sp.nx, sp.mx), dtype=torch.complex128, device=dev) for _ in range(2)]
