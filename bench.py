@@ -7,9 +7,14 @@ One "step" = one pass of the hot path over one device-resident batch of B synthe
 fields: grid_to_spec followed by spec_to_grid(.,kcos=1) (spectral.f90:98-122), FP64.
 Workload at N=1: BASELINE.json configs[1] -- T30 L8 fields, B = 6144 per GPU (SURVEY.md s8d:
 ~226 MB of grid data, far beyond L2/Infinity Cache so HBM is really exercised).
-N > 1 (torchrun, one rank per GPU): the batch index (field x level) is sharded, every rank
-transforms its own B fields, no data-path collective -> weak scaling; value = all ranks' round
-trips / max-over-ranks time.
+N > 1 (one rank per GPU): the batch index (field x level) is sharded, every rank transforms its own
+B fields, no data-path collective -> weak scaling; value = all ranks' round trips / max-over-ranks
+time.  `python bench.py --gpus N` on its own starts the N ranks itself (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started
+by a launcher (RANK / WORLD_SIZE in the environment) it runs as that rank.  The N > 1 line also
+carries `multi_gpu`: the RCCL communicator the C ABI created (spdy_comm_create), the level all-gather
+of the semi-implicit solve (implicit.f90:174-216) through it, and a level-sharded step graph with
+spdy_implicit_terms_sharded_dev captured -- timed with and without the gather, outside `value`.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
   roofline               : dominant kernel's algorithmic bytes per launch / its HIP-event launch time
@@ -265,6 +270,132 @@ def extras(s, torch, synth, sp, dev, args):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`--gpus N` with no launcher environment: start N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1) under
+    torch.distributed.run with the same arguments and hand back its exit code.  --dry-launch: the ranks only print the
+    environment the launcher gave them (works without GPUs; tests/test_host_cpu.py)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports for RCCL
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+class Watchdog:
+    """The optional N > 1 measurements issue RCCL collectives; a collective that never completes cannot be caught as an
+    exception.  If they are not done after `seconds`, rank 0 prints the headline line it already has (with the reason in
+    `multi_gpu`) and every rank leaves with os._exit(0) -- the scaling run never loses its line to a side measurement."""
+
+    def __init__(self, seconds, rank, line):
+        import threading
+        self.line, self.rank = line, rank
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.seconds = seconds
+
+    def fire(self):
+        if self.rank == 0 and self.line is not None:
+            self.line["multi_gpu"] = {"error": "timeout after %.0f s; skipped" % self.seconds}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
+    """All ranks.  What a level-sharded model step adds to the transform batch (BASELINE config 3: T30 L8,
+    fields x levels over the ranks, RCCL all-gather for the cross-level implicit solve), through the C ABI:
+      rccl_ranks          ranks of the communicator spdy_comm_create built (direct RCCL on the plan's stream)
+      allgather_levels_us one in-place all-gather of the (divdt, tdt) level blocks, eager calls
+      sharded_step        ONE captured graph per rank: this rank's share of a step's transforms (levels [lo, hi): uvspec
+                          pairs + t, tr -> grid; 3 vdspec pairs + 3 plain fields per level -> spectra), its divdt/tdt level
+                          blocks placed in the full stacks, spdy_implicit_terms_sharded_dev (gather + solve on every
+                          rank) -- and the same graph with the local solve only ("without gather")
+    The grid-space tendencies between the two batches couple the levels of a column (tendencies.f90:109-197) and would
+    need a second, grid-space exchange in a level-sharded full model: not part of this path, left out of the graph."""
+    dist = torch.distributed
+    out = {}
+    kx = sp.kx
+    sp.initialize_implicit(2400.0)
+    comm = s.sharding.LevelComm(sp)
+    out["rccl_ranks"] = comm.world
+    lo, hi = comm.level_range(kx)
+    nl = hi - lo
+    out["levels_per_rank"] = [s.sharding.shard_range(kx, r, world)[1] - s.sharding.shard_range(kx, r, world)[0] for r in range(world)]
+    c128 = lambda *sh: torch.zeros(sh, dtype=torch.complex128, device=dev)
+    f64 = lambda *sh: torch.zeros(sh, dtype=torch.float64, device=dev)
+    full = [c128(kx, sp.nx, sp.mx) for _ in range(2)]
+    psdt = c128(sp.nx, sp.mx)
+    mx_ = lambda x: s.sharding.max_over_ranks(x, dev)
+
+    def timed(fn, reps=50, warm=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return mx_((time.perf_counter() - t0) / reps * 1e6)
+
+    out["allgather_levels_us"] = timed(lambda: comm.allgather_levels_(*full))
+    out["allgather_bytes_per_rank"] = 2 * nl * sp.nx * sp.mx * 16
+    # ---- the level-sharded step as one graph per rank
+    spec = lambda n, first, sc: torch.from_numpy(synth.spectra(max(n, 1), sp.trunc, first=first) * sc).to(dev)[:n]
+    vor, div, plain = spec(nl, 1 + lo, 1e-5), spec(nl, 100 + lo, 1e-6), spec(2 * nl, 200 + 2 * lo, 1.0)
+    ngrad = 1 if rank == 0 else 0                                   # grad(ps) -> grid and the ps tendency live on rank 0
+    psi = spec(1, 400, 0.01)
+    ug, vg, pg, px, py = f64(nl, sp.il, sp.ix), f64(nl, sp.il, sp.ix), f64(2 * nl, sp.il, sp.ix), f64(1, sp.il, sp.ix), f64(1, sp.il, sp.ix)
+    P = 3 * nl
+    U, V, PL = torch.randn(P, sp.il, sp.ix, dtype=torch.float64, device=dev), torch.randn(P, sp.il, sp.ix, dtype=torch.float64, device=dev), \
+        torch.randn(P + ngrad, sp.il, sp.ix, dtype=torch.float64, device=dev)
+    pvor, pdiv, pspec = c128(P, sp.nx, sp.mx), c128(P, sp.nx, sp.mx), c128(P + ngrad, sp.nx, sp.mx)
+    side = torch.cuda.Stream(device=dev)
+    times = {}
+    with torch.cuda.stream(side):
+        sp.use_torch_stream()                       # the plan runs on `side`; torch's copies below are captured with it
+        torch.cuda.synchronize()
+        for tag, gather in (("with_gather", True), ("without_gather", False)):
+            with sp.graph_capture() as g:
+                if nl:
+                    sp.inverse_batch_grad_dev(vor, div, ug, vg, plain, pg, psi[:ngrad], px[:ngrad], py[:ngrad], kcos_pairs=2, kcos=1)
+                    sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
+                    full[0][lo:hi].copy_(pdiv[:nl])                 # divdt, tdt level blocks into the full stacks
+                    full[1][lo:hi].copy_(pdiv[nl:2 * nl])
+                if gather:
+                    comm.implicit_terms_sharded_(full[0], full[1], psdt)
+                else:
+                    sp.implicit_terms_dev(full[0], full[1], psdt)
+            times[tag] = timed(g.launch)
+            g.close()
+        side.synchronize()
+    sp.use_own_stream()
+    out["sharded_step"] = {"us_with_gather": times["with_gather"], "us_without_gather": times["without_gather"],
+                           "transforms_per_rank": (6 * nl + 2 * ngrad, 9 * nl + ngrad), "launches_in_graph": 5,
+                           "note": "per-rank graph: inverse batch, direct batch, 2 level-block copies, (RCCL all-gather +) "
+                                   "implicit_terms; max over ranks; grid-space column coupling not included"}
+    comm.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,20 +405,35 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="fields per GPU (default 6144 at T30, 1536 at T63)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the timed steps as eager launches instead of one HIP graph replay")
-    ap.add_argument("--gather", action="store_true", help="N > 1: also time the level all-gather of the sharded implicit solve (outside the timed region)")
+    ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the `multi_gpu` side measurements (RCCL all-gather, level-sharded step graph)")
+    ap.add_argument("--force-multi", action="store_true", help="run the `multi_gpu` measurements at N = 1 too (with SPDY_COMM_FORCE=1 the collectives are really issued)")
+    ap.add_argument("--multi-timeout", type=float, default=90.0, help="seconds before the `multi_gpu` measurements are abandoned")
+    ap.add_argument("--dry-launch", action="store_true", help="start the ranks, print each rank's launcher environment as JSON, exit (no GPU needed)")
     ap.add_argument("--no-extras", action="store_true", help="skip the model-shaped / operator-fused / T63 side measurements")
     ap.add_argument("--fused", type=int, default=-1, help="1 fused single-pass kernels, 0 four-kernel path, -1 auto")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # torchrun / torch.distributed.run started us
+    if not launched and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))                # one rank per GPU; this process only waits
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:                                               # never print n_gpus = 1 for --gpus 8
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_launch:
+        line = json.dumps({"rank": rank, "local_rank": local, "world_size": world, "master_addr": os.environ.get("MASTER_ADDR"),
+                           "master_port": os.environ.get("MASTER_PORT"), "hsa_ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")})
+        os.write(1, (line + "\n").encode())      # one write per rank: the ranks share the pipe
+        return
 
     import torch
     import speedy_f90_amd as s
     import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("rank %d needs GPU %d but only %d are visible (--gpus %d)" % (rank, local, torch.cuda.device_count(), args.gpus))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -353,7 +499,11 @@ def main():
         blocks.append(s.sharding.max_over_ranks(wall, dev))
         if len(blocks) >= 3 and (max(blocks[-3:]) <= 1.005 * min(blocks) or sum(blocks) > 2.0):
             break
-    elapsed = min(blocks)
+    # `value` comes from the MEDIAN of the converged tail (the last three blocks, which the loop above required to agree);
+    # the best single block is reported beside it
+    tail = sorted(blocks[-3:])
+    elapsed = tail[len(tail) // 2]
+    best_block = min(blocks)
 
     # per-kernel launch durations: HIP events on the launch stream, outside the timed region
     sp.set_profiling(True)
@@ -363,43 +513,7 @@ def main():
     prof = sp.get_profile()
     sp.set_profiling(False)
 
-    # N > 1 only, outside the timed region and best-effort: the one exchange a level-sharded model step needs --
-    # all-gather of the implicit solve's inputs over RCCL -- timed on its own so the scaling of the
-    # transform metric can be read "with and without the gather"
-    gather_ms = None
-    gather_cabi_ms = None
-    if dist and args.res == "t30" and args.gather:   # opt-in: a second RCCL communicator and extra collectives are not worth a hang in the scaling run
-        try:   # the same exchange through the C ABI (spdy_comm_*: one grouped RCCL call on the plan's stream)
-            comm = s.sharding.LevelComm(sp)
-            full = [torch.zeros((sp.kx, sp.nx, sp.mx), dtype=torch.complex128, device=dev) for _ in range(2)]
-            for _ in range(5):
-                comm.allgather_levels_(*full)
-            torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(50):
-                comm.allgather_levels_(*full)
-            torch.cuda.synchronize()
-            gather_cabi_ms = s.sharding.max_over_ranks((time.perf_counter() - t0) / 50 * 1e3, dev)
-            comm.close()
-        except Exception as e:
-            if rank == 0:
-                print("C-ABI all-gather timing skipped: %s" % e, file=sys.stderr)
-        try:
-            lo, hi = s.sharding.shard_range(sp.kx, rank, world)
-            loc = torch.zeros((hi - lo, sp.nx, sp.mx), dtype=torch.complex128, device=dev)
-            for _ in range(5):
-                s.sharding.allgather_levels(loc, sp.kx); s.sharding.allgather_levels(loc, sp.kx)
-            torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(50):
-                s.sharding.allgather_levels(loc, sp.kx); s.sharding.allgather_levels(loc, sp.kx)   # divdt and tdt
-            torch.cuda.synchronize()
-            gather_ms = s.sharding.max_over_ranks((time.perf_counter() - t0) / 50 * 1e3, dev)
-        except Exception as e:  # never let the optional measurement break the bench line
-            gather_ms = None
-            if rank == 0:
-                print("implicit all-gather timing skipped: %s" % e, file=sys.stderr)
-
+    res = None
     if rank == 0:
         ab = algorithmic_bytes(sp)
         value = world * nb * args.steps / elapsed
@@ -407,18 +521,25 @@ def main():
         dom = max(kinds, key=kinds.get)
         dom_ms = kinds[dom]
         achieved = ab[dom] * nb / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own) -- the per-field
+        # figure of the committed counter passes (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per launch / fields,
+        # source file named there) times this run's batch; `traffic_source` says so
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                per_field = json.load(open(tpath)).get(args.res, {}).get(dom)
+                tj = json.load(open(tpath))
+                per_field = tj.get(args.res, {}).get(dom)
                 traffic = per_field * nb if per_field else None
+                if traffic:
+                    traffic_source = "profiles/pmc_traffic.json (%s): rocprofv3 PMC passes of an earlier run of this command, bytes per field x %d fields; not measured in this run" % (tj.get("source", "committed"), nb)
             except Exception:
                 traffic = None
         res = {
             "metric": "spectral transforms/sec (grid<->spec round-trip) at %s L8" % args.res.upper(),
             "value": value, "unit": "round trips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "timed_blocks_s": blocks,
+            "value_from": "median of the last 3 timed blocks", "value_best_block": world * nb * args.steps / best_block,
             "timed_launch": "eager" if graph is None else "one HIP graph replay of the K steps per block", "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (%dx%d grid, trunc %d) device-resident batch of %d 2-D fields per GPU "
@@ -429,13 +550,20 @@ def main():
             "transforms_per_s": 2 * value,
             "path_hbm_frac": value / world * ab["round_trip"] / (HBM_PEAK_GBS * 1e9),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": dom_ms, "bytes_per_launch": ab[dom] * nb,
                          "all_kernels_ms": kinds},
         }
-        if world > 1:
-            res["implicit_allgather_ms"] = gather_ms   # 2 x all-gather of [kx, nx, mx] complex level slabs, per model step
-            res["implicit_allgather_cabi_ms"] = gather_cabi_ms   # the same as ONE grouped RCCL call (spdy_allgather_levels_dev)
+    # N > 1 (every rank takes part; never fatal, never inside `value`): what a level-sharded step adds
+    if (world > 1 and not args.no_multi and args.res == "t30") or args.force_multi:
+        with Watchdog(args.multi_timeout, rank, res):
+            try:
+                multi = multi_gpu_report(s, torch, synth, sp, dev, rank, world)
+            except Exception as e:
+                multi = {"error": repr(e)}
+        if rank == 0:
+            res["multi_gpu"] = multi
+    if rank == 0:
         if world == 1 and not args.no_extras:
             try:
                 res["extras"] = extras(s, torch, synth, sp, dev, args)

@@ -57,9 +57,13 @@ enum {
  * device = SPDY_DEVICE_NONE builds a host-only plan (tables only: lets CPU-side tests inspect tables; every compute
  * call on it returns SPDY_ERR_NO_DEVICE).
  * max_batch bounds nb of every batched call.  Device memory beyond the tables (< 10 MB) is allocated on demand:
- * the host-pointer entry points stage through 4 x max_batch grids from their first call on, the four-kernel path
- * (T63 small batches, other resolutions, or spdy_plan_set_fused(0)) keeps a Fourier workspace of max_batch x il x 2mx doubles.  Destroying a plan
- * also invalidates the graphs captured from it (spdy_graph_launch then returns SPDY_ERR_STATE).          */
+ * the host-pointer entry points stage through 4 x max_batch grids from their first call on; the four-kernel path
+ * (T63 direct batches under 80 fields in auto mode, spdy_plan_set_fused(0)) and the T63 operator+transform sequences
+ * keep a workspace of max_batch x (il x 2mx + 2 mx nx complex) doubles, allocated at plan creation when it is <= 64 MB
+ * (model-shaped plans: a graph capture then needs no warm-up) and at the first call that needs it otherwise (allocation
+ * inside an open capture is refused with SPDY_ERR_STATE).  Destroying a plan also invalidates the graphs captured
+ * from it (spdy_graph_launch then returns SPDY_ERR_STATE) and shuts down its communicators (spdy_comm_*: the handles
+ * stay valid for spdy_comm_destroy, every other call on them returns SPDY_ERR_STATE).                              */
 enum { SPDY_MAX_KX = 32, SPDY_DEVICE_NONE = -1, SPDY_DEVICE_AUTO = -2 };
 int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan);
 int spdy_plan_destroy(spdy_plan *plan);
@@ -207,8 +211,9 @@ int spdy_grid_tendencies_dev(spdy_plan *plan, const double *ug, const double *vg
                              double *v_out, double *plain_out);
 int spdy_tendency_combine_dev(spdy_plan *plan, double *pdiv, double *pspec);
 /* Everything after the direct batch in ONE launch (kx <= 16; the separate kernels otherwise): spdy_tendency_combine_dev,
- * spdy_spectral_tendencies_dev, spdy_implicit_terms_dev, spdy_hdiff_step_dev and spdy_step_fields_dev of ps, vor, div, t, tr,
- * with bit-identical results.  pvor/pdiv/pspec: the direct batch's outputs (the final, truncated tendencies are left in
+ * spdy_spectral_tendencies_dev, spdy_implicit_terms_dev, spdy_hdiff_step_dev and spdy_step_fields_dev of ps, vor, div, t, tr.
+ * Same expressions in the same order as the separate kernels; the results agree with them to rounding (the compiler is free
+ * to contract a*b+c differently in the two translation contexts), not necessarily bit for bit.  pvor/pdiv/pspec: the direct batch's outputs (the final, truncated tendencies are left in
  * them); vor, div, t, tr: (mx,nx,kx,2), ps: (mx,nx,2) -- time level 1 feeds the spectral tendencies and the diffusion, as
  * in the reference's leapfrog step (tendencies.f90:34-38 with alph >= 0.5, time_stepping.f90:63-96).                    */
 int spdy_spectral_step_dev(spdy_plan *plan, double *pvor, double *pdiv, double *pspec, double *vor, double *div, double *t,

@@ -43,8 +43,16 @@ build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock), $3 = o
             srcs+=("$REF/$m.f90")
         fi
     done
+    # step_field_2d / step_field_3d (time_stepping.f90:126-167) depend only on `types`, `params` and spectral%trunct, but
+    # their module also holds step(), which drags prognostics -> boundaries -> input_output -> NetCDF.  The two functions are
+    # cut out of the reference file AS THEY ARE (sed by their own first line / the module's last line) into a scratch module
+    # with the same two `use` lines the reference module has (time_stepping.f90:2-3); nothing is stubbed or rewritten.
+    {   echo "module step_field_ref"; echo "    use types, only: p"; echo "    use params"; echo "    implicit none"; echo "contains"
+        sed -n '/^    function step_field_3d/,/^end module/p' "$REF/time_stepping.f90" | sed '$d'
+        echo "end module"; } > "$tmp/step_field_ref.f90"
+    grep -q "function step_field_2d" "$tmp/step_field_ref.f90" || { echo "build_ref: step_field extraction failed"; exit 1; }
     ( cd "$tmp" && "$FC" $opt -fPIC -shared -w -Wl,-Bsymbolic -o "$OUT/libspeedy_ref_${tag}.so" \
-          "${srcs[@]}" "$HERE/ref_shim.f90" )
+          "${srcs[@]}" "$tmp/step_field_ref.f90" "$HERE/ref_shim.f90" )
     rm -rf "$tmp"
     echo "build_ref: built $OUT/libspeedy_ref_${tag}.so"
 }

@@ -346,6 +346,24 @@ class Reference(_Dims):
         d = _c128(divdt).copy(); t = _c128(tdt).copy(); p = _c128(psdt).copy()
         self.lib.ref_implicit_terms(_ptr(d), _ptr(t), _ptr(p)); return d, t, p
 
+    def wil_rob(self):
+        """params.f90:32-33 (float32 literals widened to double)."""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self.lib.ref_get_wil_rob(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def step_field(self, j1, dt, eps, field, fdt):
+        """time_stepping.f90:126-167 compiled from the reference file (build_ref.sh): field [2, kx, nx, mx] -> step_field_3d,
+        [2, nx, mx] -> step_field_2d; fdt is truncated in place like the reference's.  Returns copies (field, fdt)."""
+        f = _c128(field).copy(); d = _c128(fdt).copy()
+        if d.ndim == 3:
+            assert d.shape[0] == self.kx and f.shape[:2] == (2, self.kx)
+            fn = self.lib.ref_step_field_3d
+        else:
+            fn = self.lib.ref_step_field_2d
+        fn(ctypes.c_int(j1), ctypes.c_double(dt), ctypes.c_double(eps), _ptr(f), _ptr(d))
+        return f, d
+
     def roundtrip_loop(self, g_in, nrep=1):
         g_in = _f64(g_in); out = np.empty_like(g_in)
         self.lib.ref_roundtrip_loop(ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))

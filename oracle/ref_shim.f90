@@ -349,3 +349,34 @@ subroutine ref_geopotential(t, phis, phi) bind(C, name="ref_geopotential")
     call initialize_geopotential
     phi = get_geopotential(t, phis)
 end subroutine
+
+! time_stepping.f90:126-167 step_field_3d / step_field_2d, compiled from the reference file itself (build_ref.sh cuts the two
+! functions into the scratch module step_field_ref).  field = both time levels (mx,nx,nlev,2) in and out; fdt is truncated
+! in place as the reference does (ix == 4*iy).  nlev = kx -> step_field_3d, nlev = 1 -> step_field_2d.
+subroutine ref_step_field_3d(j1, dt, eps, field, fdt) bind(C, name="ref_step_field_3d")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use step_field_ref, only: step_field_3d
+    integer(c_int), value :: j1
+    real(c_double), value :: dt, eps
+    complex(c_double_complex), intent(inout) :: field(mx,nx,kx,2), fdt(mx,nx,kx)
+    field = step_field_3d(int(j1), dt, eps, field, fdt)
+end subroutine
+
+subroutine ref_step_field_2d(j1, dt, eps, field, fdt) bind(C, name="ref_step_field_2d")
+    use iso_c_binding
+    use params, only: mx, nx
+    use step_field_ref, only: step_field_2d
+    integer(c_int), value :: j1
+    real(c_double), value :: dt, eps
+    complex(c_double_complex), intent(inout) :: field(mx,nx,2), fdt(mx,nx)
+    field = step_field_2d(int(j1), dt, eps, field, fdt)
+end subroutine
+
+subroutine ref_get_wil_rob(o_wil, o_rob) bind(C, name="ref_get_wil_rob")
+    use iso_c_binding
+    use params, only: wil, rob
+    real(c_double), intent(out) :: o_wil, o_rob
+    o_wil = wil
+    o_rob = rob
+end subroutine

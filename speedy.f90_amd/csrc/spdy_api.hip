@@ -235,7 +235,12 @@ int upload_all(spdy_plan *p)
     void *ptr;
     // the Fourier workspace and the host-API staging buffers are allocated on demand (ensure_four / ensure_staging):
     // a device-resident T30 host needs neither (at the bench configuration they would be 1 GB)
-    if (t.trunc != 30 || p->fused_mode == 0) RC(ensure_four(p));
+    // At T63 small plans (model-shaped batches: workspace <= 64 MB) get it right away, so that a graph capture needs no
+    // warm-up call; a throughput-sized plan (1536 fields: 355 MB) allocates it at the first call that takes that path.
+    {
+        const size_t ws = (size_t)p->max_batch * (t.il * d.fs + 2 * spec_elems(p)) * sizeof(double);
+        if (p->fused_mode == 0 || (t.trunc != 30 && ws <= ((size_t)64 << 20))) RC(ensure_four(p));
+    }
     if ((rc = dev_alloc(p, sizeof(int) * (size_t)p->max_batch, &ptr))) return rc;
     p->d_kcos = static_cast<int *>(ptr);
     for (int i = 0; i < 6; ++i) {
@@ -492,6 +497,9 @@ int spdy_plan_destroy(spdy_plan *p)
         (void)hipSetDevice(p->device);
         if (p->capturing) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(p->stream, &dead); if (dead) (void)hipGraphDestroy(dead); }
         if (p->stream) (void)hipStreamSynchronize(p->stream);
+        // communicators enqueue on this plan's stream and read its dimensions: they are shut down with it (the handles stay
+        // valid for spdy_comm_destroy; every other call on them returns SPDY_ERR_STATE)
+        release_comms(p);
         for (void *a : p->allocs) (void)hipFree(a);
         if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     }

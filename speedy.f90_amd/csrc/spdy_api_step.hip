@@ -359,15 +359,47 @@ Rccl &rccl()
 }  // namespace
 
 struct spdy_comm {
-    spdy_plan *plan = nullptr;
+    spdy_plan *plan = nullptr;        // nullptr once the plan is gone: the communicator is then dead (SPDY_ERR_STATE)
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    int force = 0;                    // $SPDY_COMM_FORCE (debug): 1 = issue the collectives even with one rank,
+                                      // 2 = ... and take the ragged (per-rank broadcast) route for equal blocks too
 };
 
 #define NCCL_TRY(expr)                                                                                     \
     do {                                                                                                   \
         ncclResult_t r_ = (expr);                                                                          \
         if (r_ != ncclSuccess) return fail(SPDY_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+// inside ncclGroupStart/End: the group is closed before the error is returned (an open group would swallow or hang every
+// later collective of the process)
+#define NCCL_GROUP_TRY(expr)                                                                               \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) {                                                                           \
+            (void)rccl().GroupEnd();                                                                       \
+            return fail(SPDY_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_));                 \
+        }                                                                                                  \
+    } while (0)
+
+namespace spdy_detail {
+// Plan teardown (spdy_plan_destroy, with the plan's stream still alive and idle): the plan's communicators are shut down and
+// detached; their handles stay valid for spdy_comm_destroy, every other call on them fails with SPDY_ERR_STATE.
+void release_comms(spdy_plan *p)
+{
+    for (spdy_comm *c : p->comms) {
+        if (c->comm && rccl().handle) (void)rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+        c->plan = nullptr;
+    }
+    p->comms.clear();
+}
+}  // namespace spdy_detail
+
+#define NEED_COMM(c)                                                                                       \
+    do {                                                                                                   \
+        if (!(c)) return fail(SPDY_ERR_ARG, "null comm");                                                  \
+        if (!(c)->plan) return fail(SPDY_ERR_STATE, "the communicator's plan has been destroyed");         \
     } while (0)
 
 extern "C" {
@@ -395,11 +427,13 @@ int spdy_comm_create(spdy_plan *p, int nranks, int rank, const char *id, spdy_co
     std::memcpy(&u, id, sizeof(u));
     spdy_comm *c = new spdy_comm;
     c->plan = p; c->nranks = nranks; c->rank = rank;
+    if (const char *env = getenv("SPDY_COMM_FORCE")) c->force = atoi(env);
     ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
     if (r != ncclSuccess) {
         delete c;
         return fail(SPDY_ERR_COMM, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
     }
+    p->comms.push_back(c);
     *comm = c;
     return SPDY_OK;
 }
@@ -407,10 +441,14 @@ int spdy_comm_create(spdy_plan *p, int nranks, int rank, const char *id, spdy_co
 int spdy_comm_destroy(spdy_comm *c)
 {
     if (!c) return SPDY_OK;
-    if (c->comm && rccl().handle) {
-        (void)hipSetDevice(c->plan->device);
-        (void)hipStreamSynchronize(c->plan->stream);
-        (void)rccl().CommDestroy(c->comm);
+    if (spdy_plan *p = c->plan) {                           // still attached: drain the plan's stream, then shut RCCL down
+        for (auto it = p->comms.begin(); it != p->comms.end(); ++it)
+            if (*it == c) { p->comms.erase(it); break; }
+        if (c->comm && rccl().handle) {
+            (void)hipSetDevice(p->device);
+            if (!p->capturing) (void)hipStreamSynchronize(p->stream);
+            (void)rccl().CommDestroy(c->comm);
+        }
     }
     delete c;
     return SPDY_OK;
@@ -430,25 +468,26 @@ int spdy_comm_level_range(const spdy_comm *c, int nlev, int *lo, int *hi)
  * (each rank's block travels over its own xGMI link); ragged blocks -> one ncclBroadcast per rank and array.       */
 int spdy_allgather_levels_dev(spdy_comm *c, int nlev, int narr, double *const *d_full)
 {
-    if (!c) return fail(SPDY_ERR_ARG, "null comm");
+    NEED_COMM(c);
     spdy_plan *p = c->plan;
     NEED_DEVICE(p);
     if (narr < 0 || narr > 8 || (narr && !d_full) || nlev < 0) return fail(SPDY_ERR_ARG, "bad argument");
-    if (c->nranks == 1 || narr == 0 || nlev == 0) return SPDY_OK;
+    for (int a = 0; a < narr; ++a)
+        if (!d_full[a]) return fail(SPDY_ERR_ARG, "null array %d", a);
+    if ((c->nranks == 1 && !c->force) || narr == 0 || nlev == 0) return SPDY_OK;
     const size_t slab = spec_elems(p);                    // doubles per level
-    const bool even = nlev % c->nranks == 0;
+    const bool even = nlev % c->nranks == 0 && c->force < 2;
     NCCL_TRY(rccl().GroupStart());
     for (int a = 0; a < narr; ++a) {
-        if (!d_full[a]) { (void)rccl().GroupEnd(); return fail(SPDY_ERR_ARG, "null array %d", a); }
         if (even) {
             const size_t cnt = (size_t)(nlev / c->nranks) * slab;
-            NCCL_TRY(rccl().AllGather(d_full[a] + (size_t)c->rank * cnt, d_full[a], cnt, ncclDouble, c->comm, p->stream));
+            NCCL_GROUP_TRY(rccl().AllGather(d_full[a] + (size_t)c->rank * cnt, d_full[a], cnt, ncclDouble, c->comm, p->stream));
         } else {
             for (int r = 0; r < c->nranks; ++r) {
                 const long lo = ((long)nlev * r) / c->nranks, hi = ((long)nlev * (r + 1)) / c->nranks;
                 if (hi > lo)
-                    NCCL_TRY(rccl().Broadcast(d_full[a] + lo * slab, d_full[a] + lo * slab, (size_t)(hi - lo) * slab, ncclDouble, r,
-                                              c->comm, p->stream));
+                    NCCL_GROUP_TRY(rccl().Broadcast(d_full[a] + lo * slab, d_full[a] + lo * slab, (size_t)(hi - lo) * slab, ncclDouble, r,
+                                                    c->comm, p->stream));
             }
         }
     }
@@ -461,7 +500,7 @@ int spdy_allgather_levels_dev(spdy_comm *c, int nlev, int narr, double *const *d
  * solve on the full columns -- redundant on every rank, it is a few microseconds.                                */
 int spdy_implicit_terms_sharded_dev(spdy_comm *c, double *divdt, double *tdt, double *psdt)
 {
-    if (!c) return fail(SPDY_ERR_ARG, "null comm");
+    NEED_COMM(c);
     double *arr[2] = {divdt, tdt};
     RC(spdy_allgather_levels_dev(c, c->plan->tab.kx, 2, arr));
     return spdy_implicit_terms_dev(c->plan, divdt, tdt, psdt);

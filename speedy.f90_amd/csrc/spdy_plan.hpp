@@ -45,6 +45,7 @@ struct spdy_plan {
     struct Span { int kind; hipEvent_t t0, t1; };
     std::vector<Span> spans;
     std::vector<spdy_graph *> graphs; // graphs captured from this plan that are still alive
+    std::vector<struct spdy_comm *> comms;   // communicators created on this plan that are still alive (spdy_api_step.hip)
 };
 
 namespace spdy_detail {
@@ -58,6 +59,7 @@ int sync(spdy_plan *p);
 int ensure_staging(spdy_plan *p);     // host-pointer entry points call this first
 int ensure_four(spdy_plan *p);        // four-kernel path workspace
 int upload_level_tables(spdy_plan *p);
+void release_comms(spdy_plan *p);     // plan teardown: RCCL communicators of this plan are shut down, their handles stay valid but dead
 
 inline size_t spec_elems(const spdy_plan *p) { return (size_t)2 * p->tab.mx * p->tab.nx; }
 inline size_t grid_elems(const spdy_plan *p) { return (size_t)p->tab.ix * p->tab.il; }

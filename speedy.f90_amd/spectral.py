@@ -28,10 +28,14 @@ def _p(a):
 class Graph:
     """A captured sequence of device-resident calls (spdy_graph_* in include/spdy.h)."""
 
-    def __init__(self, lib, handle):
-        self.lib, self.h = lib, handle
+    def __init__(self, lib, handle, sp=None):
+        self.lib, self.h, self.sp = lib, handle, sp
 
     def launch(self):
+        """Replays on the plan's stream -- after re-pointing it at torch's current stream when the plan follows torch
+        (the default), so that the replay is ordered with the surrounding torch ops like every ``*_dev`` call."""
+        if self.sp is not None:
+            self.sp._sync_stream()
         check(self.lib.spdy_graph_launch(self.h))
 
     def close(self):
@@ -48,14 +52,16 @@ class Graph:
 
 class _GraphCapture:
     def __init__(self, sp):
-        self.sp, self.graph = sp, Graph(sp.lib, None)
+        self.sp, self.graph = sp, Graph(sp.lib, None, sp)
 
     def __enter__(self):
         check(self.sp.lib.spdy_graph_begin(self.sp.h))
+        self.sp._capturing = True
         return self.graph
 
     def __exit__(self, exc_type, exc, tb):
         h = ctypes.c_void_p()
+        self.sp._capturing = False
         rc = self.sp.lib.spdy_graph_end(self.sp.h, ctypes.byref(h))
         if exc_type is None:
             check(rc)
@@ -272,7 +278,8 @@ class Spectral:
         check(self.lib.spdy_plan_set_stream(self.h, None))
 
     def _sync_stream(self):
-        if not getattr(self, "_follow", True):
+        # (while a capture is open the plan's stream is pinned: spdy_plan_set_stream would fail with SPDY_ERR_STATE)
+        if not getattr(self, "_follow", True) or getattr(self, "_capturing", False):
             return
         import torch
         h = torch.cuda.current_stream().cuda_stream

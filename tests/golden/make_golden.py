@@ -30,6 +30,9 @@ tail_inputs = synth.tail_inputs   # seeded (divdt, tdt, psdt)-shaped inputs for 
 L16_SUB = (slice(None), slice(None, None, 5), slice(None, None, 3))   # the part of a [16,65,64] array kept for T63 L16
 
 
+STEP_SUB = (slice(None), slice(None, None, 2), slice(None, None, 2))   # [.., kx, nx, mx] -> every second n and m
+
+
 def geop_inputs(kx, nx, mx):
     """Seeded spectral temperature [kx,nx,mx] (~300) and surface geopotential [nx,mx] (~1000)."""
     return synth.cfield((kx, nx, mx), 5, 300.0), synth.cfield((nx, mx), 6, 1000.0)
@@ -66,6 +69,34 @@ def make_extra():
             dm = r.dmp_tables()
             d[key + "hdiff3d"] = cut(r.hdiff(t, div, dm["dmpd"], dm["dmp1d"]))
     out = os.path.join(HERE, "ref_extra.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
+def step_inputs(kx, nx, mx):
+    """Seeded prognostic-like stacks for step_field: field [2,kx,nx,mx], tendency [kx,nx,mx] (not band-limited, so that the
+    reference's trunct of the tendency matters), and the 2-D pair."""
+    return (synth.cfield((2, kx, nx, mx), 11), synth.cfield((kx, nx, mx), 12, 1e-4),
+            synth.cfield((2, nx, mx), 13), synth.cfield((nx, mx), 14, 1e-4))
+
+
+def make_step():
+    """ref_step.npz: step_field_3d / step_field_2d (time_stepping.f90:126-167) of the flang-built reference for j1 = 1
+    (forward step, eps = 0) and j1 = 2 (leapfrog + Robert-Asselin-Williams filter, eps = rob) at dt = delt and 2 delt."""
+    d = {}
+    for tag, sub in (("t30", None), ("t30k5", STEP_SUB), ("t63k16", L16_SUB)):
+        r = Reference(tag)
+        wil, rob = r.wil_rob()
+        d[tag + "_wil_rob"] = np.array([wil, rob])
+        F3, D3, F2, D2 = step_inputs(r.kx, r.nx, r.mx)
+        for j1, dt, eps in ((1, 2400.0, 0.0), (2, 4800.0, rob)):
+            key = "%s_j%d_" % (tag, j1)
+            ss = STEP_SUB if (sub is None and j1 == 1) else sub       # T30 L8: j1 = 2 complete, j1 = 1 a sub-lattice
+            cut = (lambda a, ss=ss: a[(Ellipsis,) + ss]) if ss else (lambda a: a)
+            f3, d3 = r.step_field(j1, dt, eps, F3, D3)
+            f2, d2 = r.step_field(j1, dt, eps, F2, D2)
+            d[key + "f3"], d[key + "d3"], d[key + "f2"], d[key + "d2"] = cut(f3), cut(d3), f2, d2
+    out = os.path.join(HERE, "ref_step.npz")
     np.savez_compressed(out, **d)
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
@@ -132,6 +163,10 @@ def make(tag, nb_grid, dts, imp_dts, lean):
 
 if __name__ == "__main__":
     build(quiet=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "step":      # only the step_field fixture
+        make_step()
+        sys.exit(0)
     make("t30", nb_grid=2, dts=DTS, imp_dts=(1200.0, 4800.0), lean=False)
     make("t63", nb_grid=1, dts=(4800.0,), imp_dts=(4800.0,), lean=True)
     make_extra()
+    make_step()

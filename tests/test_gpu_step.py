@@ -2,10 +2,12 @@
 (BASELINE.json config 5: T63 L16 with horizontal diffusion + implicit solve, hipGraph-captured).
 
 Checker: the C oracle.  implicit_terms, do_horizontal_diffusion, get_geopotential and all transforms/operators in it
-are pinned to flang builds of the reference (also at 16 levels); get_spectral_tendencies, the diffusion block of
-step() and step_field are restatements of tendencies.f90:242-293 / time_stepping.f90:62-167, which cannot be compiled
-here (NetCDF chain) -- PARITY UNPINNED for those three, cross-checked against NumPy readings of the same lines in
-tests/test_oracle_golden.py::test_step_restatements_selfconsistent."""
+are pinned to flang builds of the reference (also at 16 levels), and since round 3 so is step_field_2d/3d
+(time_stepping.f90:126-167: the two functions compile on their own, oracle/build_ref.sh; test_step_fields_vs_golden).
+get_spectral_tendencies and the diffusion block of step() are restatements of tendencies.f90:242-293 /
+time_stepping.f90:62-96, which cannot be compiled here (NetCDF chain) -- PARITY UNPINNED for those two, cross-checked
+against NumPy readings of the same lines in tests/test_oracle_golden.py::test_step_restatements_selfconsistent (the diffusion
+block is seven calls of the pinned do_horizontal_diffusion)."""
 import numpy as np
 import pytest
 
@@ -96,6 +98,31 @@ def test_step_entry_points_vs_oracle(tag, oracle_factory):
         # host-pointer form
         h3, hd3 = sp.step_field(j1, dt, eps, WIL, st["t"], tdt)
         ok(h3, r3); ok(hd3, rd3)
+    sp.close()
+
+
+@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+def test_step_fields_vs_golden(tag):
+    """spdy_step_fields_dev / spdy_step_field against the reference's OWN step_field_3d / step_field_2d
+    (time_stepping.f90:126-167, flang build of the two functions cut from the reference file; tests/golden/ref_step.npz):
+    j1 = 1 (forward step) and j1 = 2 (leapfrog + Robert-Asselin-Williams filter) -- pinned, not restated."""
+    import torch
+    from test_oracle_golden import STEP_CASES, STEP_J1_SUB, step_golden, step_inputs
+    z, sp = step_golden(), make_plan(tag, 64)
+    wil, rob = z[tag + "_wil_rob"]
+    F3, D3, F2, D2 = step_inputs(sp.kx, sp.nx, sp.mx)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for j1, dt, eps in ((1, 2400.0, 0.0), (2, 4800.0, rob)):
+        key = "%s_j%d_" % (tag, j1)
+        sub = STEP_CASES[tag] if STEP_CASES[tag] else (STEP_J1_SUB if j1 == 1 else None)
+        cut = (lambda a: a[(Ellipsis,) + sub]) if sub else (lambda a: a)
+        f3, d3, f2, d2 = dev(F3), dev(D3), dev(F2), dev(D2)
+        sp.step_fields_dev([(f2, d2), (f3, d3)], j1, dt, eps, wil)
+        torch.cuda.synchronize()
+        ok(cut(f3.cpu().numpy()), z[key + "f3"]); ok(f2.cpu().numpy(), z[key + "f2"])
+        assert np.array_equal(cut(d3.cpu().numpy()), z[key + "d3"]) and np.array_equal(d2.cpu().numpy(), z[key + "d2"])
+        h3, hd3 = sp.step_field(j1, dt, eps, wil, F3, D3)                       # host-pointer form
+        ok(cut(h3), z[key + "f3"]); assert np.array_equal(cut(hd3), z[key + "d3"])
     sp.close()
 
 

@@ -125,3 +125,24 @@ def test_synth_reproducible():
     s = synth.spectra(2, 30)
     assert s.shape == (2, 32, 31) and np.all(s[:, :, 0].imag == 0) and np.all(s[:, 31, :] == 0)
     assert np.all(s[0][np.add.outer(np.arange(32), np.arange(31)) > 30] == 0)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher environment starts N ranks itself (torch.distributed.run, rendezvous on
+    127.0.0.1): --dry-launch makes every rank print the environment it was given and exit, so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-launch"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ranks = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(r["rank"] for r in ranks) == [0, 1, 2]
+    assert sorted(r["local_rank"] for r in ranks) == [0, 1, 2]
+    assert all(r["world_size"] == 3 and r["master_addr"] == "127.0.0.1" and r["hsa_ipc_legacy"] == "0" for r in ranks)
+    # a launcher that started a different number of ranks than --gpus asks for is refused (never "n_gpus": 1 for --gpus 8)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-launch"],
+                         env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

@@ -5,10 +5,13 @@
 2. against the live reference library oracle/_ref (when it has been built) on extra seeds.
 The restatement is expected to be bit-exact; the assertion bar is 1e-15 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
 import synth
+from conftest import GOLDEN
 from golden.make_golden import tail_inputs
 
 EXACT = 1e-15
@@ -185,10 +188,62 @@ def test_other_level_counts_live(tag, oracle_factory):
     close(o.geopotential(T, phis), r.geopotential(T, phis))
 
 
+STEP_CASES = {"t30": None, "t30k5": (slice(None), slice(None, None, 2), slice(None, None, 2)),
+              "t63k16": (slice(None), slice(None, None, 5), slice(None, None, 3))}
+STEP_J1_SUB = (slice(None), slice(None, None, 2), slice(None, None, 2))     # T30 L8, j1 = 1 (tests/golden/make_golden.py)
+
+
+def step_golden():
+    return np.load(os.path.join(GOLDEN, "ref_step.npz"))
+
+
+def step_inputs(kx, nx, mx):
+    return (synth.cfield((2, kx, nx, mx), 11), synth.cfield((kx, nx, mx), 12, 1e-4),
+            synth.cfield((2, nx, mx), 13), synth.cfield((nx, mx), 14, 1e-4))
+
+
+@pytest.mark.parametrize("tag", sorted(STEP_CASES))
+def test_step_field_pinned(tag, oracle_factory):
+    """step_field_2d / step_field_3d (time_stepping.f90:126-167): the C oracle against the reference's own two functions,
+    compiled by flang from the reference file (oracle/build_ref.sh cuts them into a scratch module) -- golden vectors for
+    j1 = 1 (forward step) and j1 = 2 (leapfrog + Robert-Asselin-Williams filter), 8, 5 and 16 levels."""
+    z, o = step_golden(), oracle_factory(tag)
+    wil, rob = z[tag + "_wil_rob"]
+    assert wil == float(np.float32(0.53)) and rob == float(np.float32(0.05))      # params.f90:32-33: float32 literals
+    F3, D3, F2, D2 = step_inputs(o.kx, o.nx, o.mx)
+    for j1, dt, eps in ((1, 2400.0, 0.0), (2, 4800.0, rob)):
+        key = "%s_j%d_" % (tag, j1)
+        sub = STEP_CASES[tag] if STEP_CASES[tag] else (STEP_J1_SUB if j1 == 1 else None)
+        cut = (lambda a: a[(Ellipsis,) + sub]) if sub else (lambda a: a)
+        f3, d3 = o.step_field(j1, dt, eps, wil, F3, D3)
+        f2, d2 = o.step_field(j1, dt, eps, wil, F2, D2)
+        for mine, ref in ((cut(f3), z[key + "f3"]), (cut(d3), z[key + "d3"]), (f2, z[key + "f2"]), (d2, z[key + "d2"])):
+            assert mine.shape == ref.shape
+            close(mine, ref)
+        assert np.array_equal(cut(d3), z[key + "d3"]) and np.array_equal(d2, z[key + "d2"])    # trunct is exact
+
+
+def test_step_field_live(oracle_factory):
+    """The same against the live flang build, full arrays (build container only)."""
+    from oracle.pyoracle import Reference
+    if not Reference.available("t30"):
+        pytest.skip("oracle/_ref not built")
+    r, o = Reference("t30"), oracle_factory("t30")
+    if not hasattr(r.lib, "ref_step_field_3d"):
+        pytest.skip("oracle/_ref predates the step_field extraction")
+    wil, rob = r.wil_rob()
+    F3, D3, F2, D2 = step_inputs(o.kx, o.nx, o.mx)
+    for j1, dt, eps in ((1, 1200.0, 0.0), (2, 2400.0, rob), (1, 4800.0, rob)):
+        for F, D in ((F3, D3), (F2, D2)):
+            a, b = o.step_field(j1, dt, eps, wil, F, D)
+            ra, rb = r.step_field(j1, dt, eps, F, D)
+            close(a, ra); assert np.array_equal(b, rb)
+
+
 def test_step_restatements_selfconsistent(oracle_factory):
-    """get_spectral_tendencies, the diffusion block and step_field cannot be pinned (their modules need NetCDF);
-    check the restatements against independent NumPy readings of the same source lines, and against the pinned
-    pieces they are built from."""
+    """get_spectral_tendencies and the diffusion block cannot be pinned (their modules need NetCDF; step_field IS pinned,
+    test_step_field_pinned above): check the restatements against independent NumPy readings of the same source lines, and
+    against the pinned pieces they are built from."""
     o = oracle_factory("t30")
     o.tail_init(4800.0)
     kx, nx, mx = o.kx, o.nx, o.mx
