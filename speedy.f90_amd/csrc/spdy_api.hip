@@ -145,7 +145,7 @@ void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector
                                         const int n = 2 * (4 * g + k) + par, lat = CP * c + 4 * h + row;
                                         if (n < nx && m + n <= t.trunc + 1) v = P(m, n, lat);
                                     }
-                                    (dirflag ? dir : inv)[((((size_t)w * MAXS + s) * NCH + c) * 64 + lane) * 2 + h] = v;
+                                    (dirflag ? dir : inv)[((size_t)afrag(w, s, c) * 64 + lane) * 2 + h] = v;
                                 }
                     }
         }

@@ -11,8 +11,8 @@ constexpr int NLW = 4, NFW = 4, NTHR = 64 * (NLW + NFW);     // Legendre waves, 
 constexpr int NBUF = 3;                                      // chunk buffers: FFT group A, FFT group B, Legendre
 constexpr int NQ = MX / 4;                                   // 16 quads of zonal wavenumbers
 constexpr int SPEC_C = MX * NX;
-constexpr int TW = 144;                                      // ido = 48 radix-4 twiddles
-constexpr int LDS_BYTES = (NBUF * BUF + TW) * 8 + 4 * 68;     // 149,648 B (+ the zero-fill row table)
+constexpr int TW = 192;                                      // ido = 48 radix-4 twiddles, per column: [0] = (1, 0) pairs, [1..3] = wa1..wa3
+constexpr int LDS_BYTES = (NBUF * BUF + TW + IL) * 8 + 4 * 68; // 150,800 B: chunk buffers, twiddles, a per-latitude factor table, the zero-fill row table
 constexpr int MAXS = 38;                                     // slots per Legendre wave (both directions)
 
 // DIR = true: direct transform writes n <= trunc with m'+n <= trunc+1 (legendre.f90:142-154);
@@ -30,6 +30,13 @@ constexpr int slot_of(bool dir, int w, int i, int par, int g)
     return s + g;
 }
 constexpr int nslots(bool dir, int w) { return slot_of(dir, w, 4, 0, 0); }
+// A-operand image: index (in 64-lane double2 fragments) of wave w's slot s for latitude chunk c.  T63_ALAYOUT 0: [w][s][c]
+// (a chunk's fragments 6 KB apart), 1: [w][c][s] (a wave's stream for one chunk is one contiguous run)
+#ifndef T63_ALAYOUT
+#define T63_ALAYOUT 1
+#endif
+constexpr int afrag(int w, int s, int c) { return T63_ALAYOUT ? (w * NCH + c) * MAXS + s : (w * MAXS + s) * NCH + c; }
+constexpr int AFRAG_SLOT_STRIDE = T63_ALAYOUT ? 1 : NCH;    // fragments between consecutive slots of one (wave, chunk)
 static_assert(nslots(true, 0) <= MAXS && nslots(true, 1) <= MAXS && nslots(true, 2) <= MAXS && nslots(true, 3) <= MAXS, "direct slots");
 static_assert(nslots(false, 0) <= MAXS && nslots(false, 1) <= MAXS && nslots(false, 2) <= MAXS && nslots(false, 3) <= MAXS, "inverse slots");
 }  // namespace t63

@@ -19,21 +19,21 @@ o = torch.zeros_like(g)
 for _ in range(3):
     sp.grid_to_spec_dev(g, sc); sp.spec_to_grid_dev(sc, o)
 torch.cuda.synchronize()
-buf = np.zeros(2 * 8 * 24 * 6, np.int64)
+buf = np.zeros(2 * 8 * 24 * 8, np.int64)
 sp.lib.spdy_debug_t63_trace(buf.ctypes.data_as(ctypes.c_void_p))
-t = buf.reshape(2, 8, 24, 6)
+t = buf.reshape(2, 8, 24, 8)
 for k, kn in enumerate(("g2s_fused_t63", "s2g_fused_t63")):
     if not t[k].any():
         continue
     t0 = t[k][t[k] > 0].min()
-    print("==", kn, "ticks since the first mark; rows = steps, per wave: marks 0..4 (-1 = not hit)")
+    print("==", kn, "ticks since the first mark; rows = steps, per wave: marks 0..6 (-1 = not hit)")
     for wv in range(8):
         if not t[k, wv].any():
             continue
         print(" wave", wv)
         for st in range(24):
             if t[k, wv, st].any():
-                print("   step %2d " % st, " ".join("%7d" % (v - t0 if v > 0 else -1) for v in t[k, wv, st, :5]))
+                print("   step %2d " % st, " ".join("%7d" % (v - t0 if v > 0 else -1) for v in t[k, wv, st, :7]))
 sp.set_profiling(True)
 for _ in range(5):
     sp.grid_to_spec_dev(g, sc); sp.spec_to_grid_dev(sc, o)
