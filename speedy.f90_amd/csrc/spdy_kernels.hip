@@ -47,9 +47,9 @@ template <> __device__ __forceinline__ const FftConstants &fftc<192>() { return 
 // p = index of a real part (1,3,5..), p+1 its imaginary part, (q,q+1) = (ido-2-p, ido-1-p) the
 // conjugate-mirrored pair.  All indices are compile-time after unrolling -> pure VGPR code.
 // ------------------------------------------------------------------------------------------
-template <int IDO, int L1>
+template <int IDO, int L1, class W>
 __device__ __forceinline__ void bwd4(const double (&in)[IDO * 4 * L1], double (&out)[IDO * 4 * L1],
-                                     const double *w, double sqrt2)
+                                     const W &w, double sqrt2)
 {
 #define I4(i, j, k) in[(i) + IDO * ((j) + 4 * (k))]
 #define O4(i, k, j) out[(i) + IDO * ((k) + L1 * (j))]
@@ -114,9 +114,9 @@ __device__ __forceinline__ void fwd3_ido1(const double (&in)[3 * L1], double (&o
     }
 }
 
-template <int IDO, int L1>
+template <int IDO, int L1, class W>
 __device__ __forceinline__ void fwd4(const double (&in)[IDO * 4 * L1], double (&out)[IDO * 4 * L1],
-                                     const double *w, double hsqt2)
+                                     const W &w, double hsqt2)
 {
 #define I4(i, k, j) in[(i) + IDO * ((k) + L1 * (j))]
 #define O4(i, j, k) out[(i) + IDO * ((j) + 4 * (k))]
@@ -172,6 +172,47 @@ __device__ __forceinline__ void sub48_forward_c(const FftConstants &c, double (&
     fwd3_ido1<16>(x, y, c.taui);
     fwd4<3, 4>(y, x, c.b, c.hsqt2);
     fwd4<12, 1>(x, y, c.a, c.hsqt2);
+}
+
+// The 49 stage constants of the 48-point sub-transforms ({a[36], b[9], taui, sqrt2, hsqt2, scale} of FftConstants) held in
+// TWO VGPRs -- dword i in lane i -- and picked out with v_readlane (lane index = compile-time immediate, result = an SGPR
+// operand of the FP64 instruction).  As scalar loads from constant memory the compiler fetches them just in time, in ~10
+// groups per sub-transform (there are not 98 free SGPRs), and every group is an exposed scalar-cache round trip -- ~2 k
+// ticks of a 48-point transform whose arithmetic takes 1.3 k.
+struct LaneConst {
+    unsigned t0, t1;
+    __device__ __forceinline__ void load(const FftConstants &c, int lane)
+    {
+        const unsigned *d = reinterpret_cast<const unsigned *>(c.a);
+        t0 = d[lane];
+        t1 = lane < 34 ? d[64 + lane] : 0u;
+    }
+    __device__ __forceinline__ double get(int i) const
+    {
+        const int d = 2 * i;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(d < 64 ? t0 : t1), d & 63);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(d + 1 < 64 ? t0 : t1), (d + 1) & 63);
+        return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    }
+};
+struct LaneTab {
+    LaneConst c;
+    int base;
+    __device__ __forceinline__ double operator[](int i) const { return c.get(base + i); }
+};
+__device__ __forceinline__ void sub48_backward_l(const LaneConst &lc, double (&x)[48], double (&y)[48])
+{
+    const double sqrt2 = lc.get(46);
+    bwd4<12, 1>(x, y, LaneTab{lc, 0}, sqrt2);
+    bwd4<3, 4>(y, x, LaneTab{lc, 36}, sqrt2);
+    bwd3_ido1<16>(x, y, lc.get(45));
+}
+__device__ __forceinline__ void sub48_forward_l(const LaneConst &lc, double (&x)[48], double (&y)[48])
+{
+    const double hsqt2 = lc.get(47);
+    fwd3_ido1<16>(x, y, lc.get(45));
+    fwd4<3, 4>(y, x, LaneTab{lc, 36}, hsqt2);
+    fwd4<12, 1>(x, y, LaneTab{lc, 0}, hsqt2);
 }
 
 template <int NF>
