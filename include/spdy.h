@@ -267,6 +267,20 @@ int spdy_direct_batch_dev(spdy_plan *plan, int npairs, const double *d_ug, const
 int spdy_inverse_batch_grad_dev(spdy_plan *plan, int npairs, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
                                 int kcos_pairs, int nplain, const double *d_spec, const int *d_kcos, int kcos_all, double *d_grid,
                                 int ngrad, const double *d_psi, double *d_gx, double *d_gy, int kcos_grad);
+/* The same with the plain spectra taken from up to SPDY_MAX_SPEC_SEGS separate device arrays -- the reference reads vor, div,
+ * t, tr of time level j2 straight from its four prognostic arrays (tendencies.f90:89-101), so a captured time step needs no
+ * gather copy in front of this call.  Segment i contributes segs[i].nb fields; the grids of all segments are ONE stack
+ * d_grid (sum of nb fields, in segment order); d_kcos (optional) is indexed along that stack.  Still one launch at T30 (the
+ * mixed kernel looks the source array up per field) and one fused launch at T63 (one segment of the launch each).
+ * ngrad may be 0.                                                                                                  */
+enum { SPDY_MAX_SPEC_SEGS = 4 };
+typedef struct {
+    int nb;
+    const double *d_spec;
+} spdy_spec_seg;
+int spdy_inverse_batch_segs_dev(spdy_plan *plan, int npairs, const double *d_vor, const double *d_div, double *d_ug, double *d_vg,
+                                int kcos_pairs, int nseg, const spdy_spec_seg *segs, const int *d_kcos, int kcos_all, double *d_grid,
+                                int ngrad, const double *d_psi, double *d_gx, double *d_gy, int kcos_grad);
 /* the same with host pointers (one H2D + one D2H round trip for a whole level stack) */
 int spdy_uvspec_to_grid(spdy_plan *plan, int nb, const double *vor, const double *div, double *ug, double *vg, int kcos);
 int spdy_grad_to_grid(spdy_plan *plan, int nb, const double *psi, double *gx, double *gy, int kcos);

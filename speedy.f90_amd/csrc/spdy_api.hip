@@ -905,6 +905,72 @@ int spdy_inverse_batch_grad_dev(spdy_plan *p, int npairs, const double *vor, con
     return SPDY_OK;
 }
 
+int spdy_inverse_batch_segs_dev(spdy_plan *p, int npairs, const double *vor, const double *dv, double *ug, double *vg, int kcos_pairs,
+                                int nseg, const spdy_spec_seg *segs, const int *d_kcos, int kcos_all, double *grid,
+                                int ngrad, const double *psi, double *gx, double *gy, int kcos_grad)
+{
+    NEED_DEVICE(p);
+    if (nseg < 0 || nseg > SPDY_MAX_SPEC_SEGS || (nseg && !segs)) return fail(SPDY_ERR_ARG, "0..SPDY_MAX_SPEC_SEGS segments");
+    // drop empty segments, total the plain fields
+    spdy_spec_seg sg[SPDY_MAX_SPEC_SEGS];
+    int ns = 0, nplain = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].nb < 0) return fail(SPDY_ERR_ARG, "negative segment size");
+        if (segs[i].nb == 0) continue;
+        if (!segs[i].d_spec) return fail(SPDY_ERR_ARG, "null device pointer");
+        sg[ns++] = segs[i];
+        nplain += segs[i].nb;
+    }
+    if (ns <= 1)
+        return spdy_inverse_batch_grad_dev(p, npairs, vor, dv, ug, vg, kcos_pairs, nplain, ns ? sg[0].d_spec : nullptr, d_kcos, kcos_all, grid,
+                                           ngrad, psi, gx, gy, kcos_grad);
+    RC(check_batch(p, npairs));
+    RC(check_batch(p, nplain));
+    RC(check_batch(p, ngrad));
+    if ((npairs && (!vor || !dv || !ug || !vg)) || !grid || (ngrad && (!psi || !gx || !gy))) return fail(SPDY_ERR_ARG, "null device pointer");
+    kcos_pairs = kcos_pairs == 1 ? 1 : 2;
+    kcos_grad = kcos_grad == 1 ? 1 : 2;
+    if (use_fused(p, npairs) && npairs > 0) {                                 // T30: one mixed launch, source array looked up per field
+        spdy::PlainSegs ps{{nullptr, nullptr, nullptr}, {0x7fffffff, 0x7fffffff, 0x7fffffff}};
+        for (int i = 1, first = sg[0].nb; i < ns; first += sg[i].nb, ++i) { ps.spec[i - 1] = sg[i].d_spec; ps.first[i - 1] = first; }
+        return timed(p, SPDY_K_S2G_FUSED, [&] {
+            return spdy::launch_s2g_fused(p->dev, npairs, vor, nullptr, kcos_pairs, ug, p->num_cu * p->wg_per_cu, p->stream, 3, dv, vg,
+                                          nplain, sg[0].d_spec, d_kcos, kcos_all, grid, ngrad, psi, gx, gy, kcos_grad, p->d_zero_spec, &ps);
+        });
+    }
+    if (use_fused63_composite(p) && npairs > 0 && npairs + ngrad <= p->max_batch) {
+        // T63: one operator launch (uvspec | grad), then U, V, the gradient pair and every source array are segments of ONE fused launch
+        RC(ensure_four(p));
+        const size_t off = (size_t)npairs * spec_elems(p);
+        if (ngrad) KERNEL(spdy::launch_uvspec_grad(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
+        else KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
+        spdy::T63Batch b{};
+        int k = 0;
+        b.seg[k++] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        b.seg[k++] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        size_t first = 0;
+        for (int i = 0; i < ns; ++i) {
+            b.seg[k++] = spdy::T63Seg{sg[i].d_spec, grid + first * grid_elems(p), nullptr, d_kcos ? d_kcos + first : nullptr, sg[i].nb, kcos_all, 0, 0};
+            first += sg[i].nb;
+        }
+        if (ngrad) {
+            b.seg[k++] = spdy::T63Seg{p->tmp_c + off, gx, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
+            b.seg[k++] = spdy::T63Seg{p->tmp_d + off, gy, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
+        }
+        b.nseg = k;
+        return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
+    }
+    // any other plan: the separate calls
+    if (npairs) RC(spdy_uvspec_to_grid_dev(p, npairs, vor, dv, ug, vg, kcos_pairs));
+    size_t first = 0;
+    for (int i = 0; i < ns; ++i) {
+        RC(spdy_spec_to_grid_dev(p, sg[i].nb, sg[i].d_spec, d_kcos ? d_kcos + first : nullptr, kcos_all, grid + first * grid_elems(p)));
+        first += sg[i].nb;
+    }
+    if (ngrad) RC(spdy_grad_to_grid_dev(p, ngrad, psi, gx, gy, kcos_grad));
+    return SPDY_OK;
+}
+
 int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const double *vg, double *vorm, double *divm, int kcos,
                           int nplain, const double *grid, double *spec)
 {

@@ -68,11 +68,13 @@ hipError_t launch_fourier_dir(const DevPlan &p, int nb, const double *grid, cons
 // kcos_all applies to both outputs.
 // mode 3: a model step's whole inverse batch in one launch -- nb (vor, div) pairs as in mode 1 plus nplain ordinary
 // fields spec_p -> grid_p with their own kcos (kcos_p per field, or kcos_all_p)
+// mode 3: further source arrays of the plain spectra (S2gMixed::seg_spec / seg_first; first = 0x7fffffff: unused)
+struct PlainSegs { const double *spec[3]; int first[3]; };
 hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid,
                             int max_wg, hipStream_t s, int mode = 0, const double *spec2 = nullptr, double *grid2 = nullptr,
                             int nplain = 0, const double *spec_p = nullptr, const int *kcos_p = nullptr, int kcos_all_p = 1,
                             double *grid_p = nullptr, int ngrad = 0, const double *psi = nullptr, double *gx = nullptr,
-                            double *gy = nullptr, int kcos_grad = 2, const double *zero = nullptr);
+                            double *gy = nullptr, int kcos_grad = 2, const double *zero = nullptr, const PlainSegs *segs = nullptr);
 // (mode 3, ngrad > 0: gradient tiles psi[i] -> gx[i], gy[i] ride along as uvspec tiles with vor = `zero` and the grad tables)
 // grid2 / spec2 non-null: vdspec in one pass -- tile i is the pair (grid[i], grid2[i]) scaled by gscale, the
 // outputs are vds of the pair's spectra: vorticity -> spec, divergence -> spec2 (nb pairs)
@@ -87,7 +89,7 @@ hipError_t launch_s2g_fused_t63(const DevPlan &p, int nb, const double *spec, co
                                 hipStream_t s);
 // One fused T63 launch over up to six independent sub-batches (own arrays, own scale / kcos policy); pair0 and npairs are
 // filled in by the launcher
-constexpr int T63_MAX_SEG = 6;
+constexpr int T63_MAX_SEG = 8;
 struct T63Seg {
     const double *src;
     double *dst;

@@ -370,6 +370,22 @@ class Spectral:
                                                    self._dp(d_kcos) if d_kcos is not None else None, int(kcos), self._dp(grid),
                                                    psi.shape[0], self._dp(psi), self._dp(gx), self._dp(gy), int(kcos_grad)))
 
+    def inverse_batch_segs_dev(self, vor, div, ug, vg, specs, grid, psi=None, gx=None, gy=None, kcos_pairs=2, kcos=1, d_kcos=None, kcos_grad=2):
+        """inverse_batch_grad_dev with the plain spectra in up to four separate arrays `specs` (tendencies.f90:89-101 reads
+        vor, div, t, tr from four prognostic arrays); their grids are the one stack `grid`.  psi / gx / gy optional."""
+        self._sync_stream()
+        import ctypes
+
+        class Seg(ctypes.Structure):
+            _fields_ = [("nb", ctypes.c_int), ("d_spec", ctypes.c_void_p)]
+        segs = (Seg * len(specs))(*[Seg(int(x.shape[0]), self._dp(x)) for x in specs])
+        ngrad = 0 if psi is None else psi.shape[0]
+        check(self.lib.spdy_inverse_batch_segs_dev(self.h, vor.shape[0], self._dp(vor), self._dp(div), self._dp(ug), self._dp(vg),
+                                                   int(kcos_pairs), len(specs), ctypes.cast(segs, ctypes.c_void_p),
+                                                   self._dp(d_kcos) if d_kcos is not None else None, int(kcos), self._dp(grid),
+                                                   ngrad, self._dp(psi) if ngrad else None, self._dp(gx) if ngrad else None,
+                                                   self._dp(gy) if ngrad else None, int(kcos_grad)))
+
     def direct_batch_dev(self, ug, vg, vor, div, grid, spec, kcos=2):
         """vdspec of the (ug, vg) pairs and grid_to_spec of `grid` in one launch (a model step's direct batch)."""
         self._sync_stream()

@@ -213,3 +213,46 @@ def test_inverse_batch_with_gradient(res, npairs, nplain, ngrad):
         else:
             assert torch.equal(a, b)
     sp.close()
+
+
+@pytest.mark.parametrize("res,npairs,segsizes,ngrad", [("t30", 8, (8, 8, 8, 8), 1), ("t30", 5, (5, 5, 5, 5), 1), ("t30", 7, (7, 1, 3, 2), 0),
+                                                       ("t30", 3, (1, 0, 4), 2), ("t30", 300, (299, 301), 7),
+                                                       ("t63f", 16, (16, 16, 16, 16), 1), ("t63f", 5, (5, 3, 1, 2), 0), ("t63", 3, (2, 3), 1)])
+def test_inverse_batch_segments(res, npairs, segsizes, ngrad):
+    """spdy_inverse_batch_segs_dev: the plain spectra read in place from up to four separate arrays (what tendencies.f90:89-101
+    does with vor, div, t, tr) must give the bits of the single-array call on the concatenated stack -- odd segment sizes put
+    the two fields of a T30 tile (and of a T63 pair at a segment's end) in different arrays."""
+    import torch
+    import speedy_f90_amd as s
+    nplain = sum(segsizes)
+    sp = s.Spectral(res[:3], kx=8, max_batch=max(npairs + ngrad, nplain, 8), device=0)
+    if res.endswith("f"):
+        sp.set_fused(1)
+    S = torch.from_numpy(synth.spectra(2 * npairs + nplain + max(ngrad, 1), sp.trunc, first=6400, full_rows=True)).cuda()
+    vor, div, spl, psi = S[:npairs], S[npairs:2 * npairs], S[2 * npairs:2 * npairs + nplain], S[2 * npairs + nplain:][:ngrad]
+    # separate allocations, so that nothing is contiguous by accident
+    parts, first = [], 0
+    for n in segsizes:
+        parts.append(spl[first:first + n].clone())
+        first += n
+    gs = (sp.il, sp.ix)
+    sizes = (npairs, npairs, nplain, ngrad, ngrad)
+    want = [torch.zeros((n,) + gs, dtype=torch.float64, device="cuda") for n in sizes]
+    got = [torch.full((n,) + gs, float("nan"), dtype=torch.float64, device="cuda") for n in sizes]
+    if ngrad:
+        sp.inverse_batch_grad_dev(vor, div, want[0], want[1], spl, want[2], psi, want[3], want[4], kcos_pairs=2, kcos=1)
+        sp.inverse_batch_segs_dev(vor, div, got[0], got[1], parts, got[2], psi, got[3], got[4], kcos_pairs=2, kcos=1)
+    else:
+        sp.inverse_batch_dev(vor, div, want[0], want[1], spl, want[2], kcos_pairs=2, kcos=1)
+        sp.inverse_batch_segs_dev(vor, div, got[0], got[1], parts, got[2], kcos_pairs=2, kcos=1)
+    sp.synchronize()
+    for a, b in zip(got, want):
+        if a.numel() == 0:
+            continue
+        if res.startswith("t63"):
+            # a T63 pair is formed inside a segment: odd segments pair fields differently from the concatenated stack, and a
+            # field's bits do not depend on its partner (tests/test_gpu_determinism.py) -- equal to rounding is the contract here
+            ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
+        else:
+            assert torch.equal(a, b)
+    sp.close()
