@@ -269,7 +269,62 @@ def extras(s, torch, synth, sp, dev, args):
     out[other + "_round_trip"] = {"fields": nb2, "round_trips_per_s": nb2 / (us * 1e-6), "us_per_step": us, "kernel_us": prof,
                                   "path_hbm_frac": gb(byt, us) / HBM_PEAK_GBS}
     sp2.close()
+    del g2, s2, o2
+    if not args.no_cpu_baseline:
+        # the reference's own CPU path at the other resolution too (same sources, params.f90:19-26 edited; one core)
+        try:
+            cb = cpu_baseline(other, sample_fields=32 if other == "t63" else 256, target_s=5.0)
+            out[other + "_round_trip"]["cpu_baseline"] = cb
+            out[other + "_round_trip"]["gpu_over_cpu_core"] = out[other + "_round_trip"]["round_trips_per_s"] / cb["value"]
+        except Exception as e:
+            out[other + "_round_trip"]["cpu_baseline"] = {"error": repr(e)}
+    # the all-HBM rate: a batch whose spectra (390 MB at T30) no longer fit the 256 MB Infinity Cache between the two kernels
+    if sp.trunc == 30:
+        try:
+            nbig = 24576
+            spb = s.Spectral("t30", kx=8, max_batch=nbig, device=dev.index or 0)
+            spb.use_own_stream()
+            gb_ = torch.randn((nbig, spb.il, spb.ix), dtype=torch.float64, device=dev)
+            sb_ = torch.zeros((nbig, spb.nx, spb.mx), dtype=torch.complex128, device=dev)
+            ob_ = torch.zeros_like(gb_)
+            torch.cuda.synchronize()
+
+            def rtb():
+                spb.grid_to_spec_dev(gb_, sb_)
+                spb.spec_to_grid_dev(sb_, ob_, kcos=1)
+            usb = _time_us(torch, spb, rtb, reps=20, warm=10)
+            bytb = 2 * nbig * (spb.ix * spb.il * 8 + spb.mx * spb.nx * 16)
+            out["round_trip_b24576"] = {"fields": nbig, "round_trips_per_s": nbig / (usb * 1e-6), "us_per_step": usb,
+                                        "path_hbm_frac": gb(bytb, usb) / HBM_PEAK_GBS,
+                                        "note": "spectra buffer 390 MB > 256 MB Infinity Cache: nothing of a step stays on die"}
+            spb.close()
+            del gb_, sb_, ob_
+        except Exception as e:
+            out["round_trip_b24576"] = {"error": repr(e)}
+    # the HOST-pointer drop-in as a Fortran host sees it (PCIe + syncs included; never `value`): the stock one-field-per-call
+    # pattern of spectral.f90:98-122 and the level-stack extension, through the flang-built drop-in modules
+    out["host_pointer_dropin"] = host_pointer_dropin()
     return out
+
+
+def host_pointer_dropin():
+    import subprocess
+    res = {}
+    for tag in ("t30", "t63"):
+        exe = os.path.join(ROOT, "speedy.f90_amd", "fortran", "build", tag, "dropin_rate")
+        if not os.path.exists(exe):
+            res[tag] = {"error": "fortran/build/%s/dropin_rate not built (flang absent at build time)" % tag}
+            continue
+        try:
+            o = subprocess.run([exe, "30" if tag == "t30" else "10"], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, SPDY_DEVICE="0"))
+            f = o.stdout.split()
+            res[tag] = {"per_field_calls_round_trips_per_s": float(f[0]), "level_stack_calls_round_trips_per_s": float(f[1]),
+                        "fields_per_stack": int(f[3]),
+                        "what": "Fortran host arrays -> drop-in spectral module -> C ABI (H2D, kernels, D2H, sync per call)"}
+        except Exception as e:
+            res[tag] = {"error": repr(e)}
+    return res
 
 
 def _free_port():
