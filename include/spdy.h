@@ -58,7 +58,7 @@ enum {
  * call on it returns SPDY_ERR_NO_DEVICE).
  * max_batch bounds nb of every batched call.  Device memory beyond the tables (< 10 MB) is allocated on demand:
  * the host-pointer entry points stage through 4 x max_batch grids from their first call on; the four-kernel path
- * (T63 direct batches under 80 fields in auto mode, spdy_plan_set_fused(0)) and the T63 operator+transform sequences
+ * (spdy_plan_set_fused(0)) and the T63 operator+transform sequences
  * keep a workspace of max_batch x (il x 2mx + 2 mx nx complex) doubles, allocated at plan creation when it is <= 64 MB
  * (model-shaped plans: a graph capture then needs no warm-up) and at the first call that needs it otherwise (allocation
  * inside an open capture is refused with SPDY_ERR_STATE).  Destroying a plan also invalidates the graphs captured
@@ -81,10 +81,10 @@ int spdy_plan_synchronize(spdy_plan *plan);
 enum { SPDY_K_LEGENDRE_INV = 0, SPDY_K_FOURIER_INV = 1, SPDY_K_FOURIER_DIR = 2, SPDY_K_LEGENDRE_DIR = 3,
        SPDY_K_S2G_FUSED = 4, SPDY_K_G2S_FUSED = 5, SPDY_K_COUNT = 6 };
 int spdy_plan_set_profiling(spdy_plan *plan, int on);
-/* Kernel selection for the transforms: 1 = fused single-pass kernels (T30, T63), 0 = the four-kernel path (any
- * resolution), -1 (default) = fused, except T63 grid_to_spec batches under 80 fields, which take the four-kernel path
- * (lower latency there).  The two paths agree to rounding, not bitwise: pin 1 or 0 when a field's bits must not depend on
- * the size of the batch it travels in.  Fused launches whose grid-side array is >= 16 MB stream it with
+/* Kernel selection for the transforms: 1 and -1 (default) = fused single-pass kernels (T30, T63) at every batch size,
+ * 0 = the four-kernel path (any resolution; the only path for other resolutions).  The two paths agree to rounding, not
+ * bitwise; within one setting a field's bits never depend on the size or composition of the batch it travels in
+ * (tests/test_gpu_determinism.py).  Fused launches whose grid-side array is >= 16 MB stream it with
  * non-temporal loads/stores (the data passes through the caches once); smaller ones leave it cached for their
  * consumer.                                                                                        */
 int spdy_plan_set_fused(spdy_plan *plan, int mode);

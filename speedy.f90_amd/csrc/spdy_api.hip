@@ -391,12 +391,13 @@ bool use_fused(const spdy_plan *p, int nb)
 // T63: fused field-pair kernels for the plain transforms (spdy_fused_t63.inc); the operator-fused modes use the
 // multi-kernel sequences
 // T63, direct transform: below ~80 fields a launch is one field pair per workgroup on a fraction of the CUs and costs the
-// pair's pipeline latency (26-27 us, tools/t63_small_batch.py); the four-kernel pipeline spreads such a batch over more
-// workgroups (21-24 us), so "auto" takes it there.  The two paths agree to rounding, not bitwise: spdy_plan_set_fused(1)
-// (or 0) pins one path, and with it a field's bits, for every batch size (tests/test_gpu_determinism.py).
-// The inverse transform has no such threshold: its small batches run the fused kernel by (pair, chunk) items
-// (12-13 us against 20-25 us for the four-kernel pipeline).
-bool use_fused63(const spdy_plan *p, int nb) { return p->tab.trunc == 63 && p->fused_mode != 0 && (nb >= 80 || p->fused_mode == 1); }
+// pair's pipeline latency (26 us, tools/t63_small_batch.py); the four-kernel pipeline spreads such a batch over more
+// workgroups (21-24 us).  Until round 3 "auto" switched to it there -- and with it a field's BITS depended on whether it
+// travelled in a batch of 79 or 80 (the two paths agree to rounding, not bitwise).  A drop-in must not do that to its host:
+// auto now means the fused kernels at every batch size (the whole-pair walk accumulates every field the same way whatever
+// the batch; the inverse transform's by-chunk walk for small batches is bit-identical to its whole-pair walk), at the price
+// of ~4 us on a lone small direct transform.  spdy_plan_set_fused(0) still selects the four-kernel path.
+bool use_fused63(const spdy_plan *p, int nb) { (void)nb; return p->tab.trunc == 63 && p->fused_mode != 0; }
 // The composite entry points (uvspec/grad -> grid, vdspec, the mixed batches) are one fused launch against two to four
 // four-kernel sequences: the fused kernels win there at any size.
 bool use_fused63_composite(const spdy_plan *p) { return p->tab.trunc == 63 && p->fused_mode != 0; }

@@ -290,7 +290,7 @@ class Spectral:
     KERNEL_KINDS = ("legendre_inv", "fourier_inv", "fourier_dir", "legendre_dir", "s2g_fused", "g2s_fused")
 
     def set_fused(self, mode):
-        """1 = fused single-pass kernels (T30), 0 = four-kernel path, -1 = automatic by batch size."""
+        """1 / -1 (default) = fused single-pass kernels (T30, T63) at every batch size, 0 = four-kernel path."""
         check(self.lib.spdy_plan_set_fused(self.h, int(mode)))
 
     def set_profiling(self, on=True):

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("res,fused,sizes", [("t30", 1, (1, 2, 3, 255, 256, 257, 455, 457, 511, 513, 1031, 2049)),   # 455 | 457: either side of the 16 MB streaming threshold
                                               ("t30", 0, (1, 7, 65, 513)),
-                                              ("t63", 1, (1, 9, 65, 200, 300)),   # pinned paths (auto: the direct transform switches at 80 fields); 300 = whole-pair walk of the inverse kernel, the others by-chunk
+                                              ("t63", 1, (1, 9, 65, 200, 300)),   # 300 = whole-pair walk of the inverse kernel, the others by-chunk
+                                              ("t63", -1, (1, 9, 79, 80, 300)),  # auto mode: no path switch with the batch size any more (round 3)
                                               ("t63", 0, (1, 9, 65))])
 def test_repeatable_and_position_independent(res, fused, sizes):
     import torch

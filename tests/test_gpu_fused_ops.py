@@ -135,7 +135,7 @@ def test_hdiff_multi_equals_separate_calls(oracle_factory):
                                                ("t63f", 3, 5), ("t63f", 1, 1), ("t63f", 48, 49)])
 def test_direct_batch_one_launch(res, npairs, nplain):
     """spdy_direct_batch_dev = vdspec of the pairs + grid_to_spec of the plain fields, bit for bit.  t63f = fused kernels
-    pinned (spdy_plan_set_fused(1)): the batch is ONE three-segment launch (+ vds), as it is from 80 fields in auto mode."""
+    pinned (spdy_plan_set_fused(1)): the batch is ONE three-segment launch (+ vds), as it is in auto mode."""
     import torch
     import speedy_f90_amd as s
     sp = s.Spectral(res[:3], kx=8, max_batch=max(npairs, nplain, 8), device=0)
@@ -151,7 +151,7 @@ def test_direct_batch_one_launch(res, npairs, nplain):
     sp.direct_batch_dev(ug, vg, got[0], got[1], gp, got[2], 2)
     sp.synchronize()
     for a, b in zip(got, want):
-        if res == "t63":     # auto mode: the plain fields of `want` (under 80) took the four-kernel path -- equal to rounding
+        if res == "t63":     # the separate calls form other field pairs than the one launch (pairs are formed inside a segment) -- equal to rounding is the contract
             ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
         else:
             assert torch.equal(a, b)
@@ -179,7 +179,7 @@ def test_inverse_batch_one_launch(res, npairs, nplain):
     sp.inverse_batch_dev(vor, div, got[0], got[1], spl, got[2], kcos_pairs=2, d_kcos=kc)
     sp.synchronize()
     for a, b in zip(got, want):
-        if res == "t63":     # auto mode: the plain fields of `want` (under 80) took the four-kernel path -- equal to rounding
+        if res == "t63":     # the separate calls form other field pairs than the one launch (pairs are formed inside a segment) -- equal to rounding is the contract
             ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
         else:
             assert torch.equal(a, b)
@@ -208,7 +208,7 @@ def test_inverse_batch_with_gradient(res, npairs, nplain, ngrad):
     sp.inverse_batch_grad_dev(vor, div, got[0], got[1], spl, got[2], psi, got[3], got[4], kcos_pairs=2, kcos=1, kcos_grad=kg)
     sp.synchronize()
     for a, b in zip(got, want):
-        if res == "t63":     # auto mode: small separate calls take the four-kernel path -- equal to rounding
+        if res == "t63":     # the separate calls form other field pairs than the one launch -- equal to rounding is the contract
             ok(a.cpu().numpy(), b.cpu().numpy(), 1e-13)
         else:
             assert torch.equal(a, b)
