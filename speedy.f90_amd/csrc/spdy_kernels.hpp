@@ -95,8 +95,12 @@ struct T63Seg {
     double *dst;
     const double *scale;   // direct: per-latitude factor applied on load, or nullptr
     const int *kcos;       // inverse: per-field kcos (device), or nullptr for kcos_all
-    int nb, kcos_all, pair0, pad;
+    int nb, kcos_all, pair0;
+    int op;                // inverse: 0 = src holds the spectra; T63_OP_* = they are derived from src / (const double *)scale on load
 };
+// spectral operators folded into the inverse kernel's operand load (spectral.f90:124-196): the segment's spectra are
+//   U / V of uvspec(vor = src, div = scale)  or  d/dlambda / d/dmu of grad(psi = src)
+enum { T63_OP_NONE = 0, T63_OP_U = 1, T63_OP_V = 2, T63_OP_GX = 3, T63_OP_GY = 4 };
 struct T63Batch {
     int nseg, npairs;
     int by_chunk, pad;     // inverse, small batches: work items are (pair, chunk) instead of whole pairs (set by the launcher)
