@@ -219,6 +219,16 @@ int spdy_tendency_combine_dev(spdy_plan *plan, double *pdiv, double *pspec);
 int spdy_spectral_step_dev(spdy_plan *plan, double *pvor, double *pdiv, double *pspec, double *vor, double *div, double *t,
                            double *tr, double *ps, const double *phis, const double *d_tcorh, const double *d_qcorh, double sdrag,
                            int j1, double dt, double eps, double wil, double *phi);
+/* spdy_direct_batch_dev(3 kx pairs ug, vg -> pvor, pdiv; 3 kx + 1 plain fields d_grid -> pspec) followed by
+ * spdy_spectral_step_dev, as ONE call: the second half of a time step (tendencies.f90:212-234, :242-293,
+ * implicit.f90:168-217, time_stepping.f90:62-167).  At T30 exactly those two calls; at T63, where vds is not part of the
+ * transform kernel, the pairs' spectra stay in the plan's temporaries and vds (spectral.f90:146-171) is applied where the
+ * spectral step reads them: 2 launches instead of 3.  pvor, pdiv, pspec receive the truncated tendencies as with the
+ * separate calls; results agree with them to rounding.                                                              */
+int spdy_direct_batch_spectral_step_dev(spdy_plan *plan, const double *d_ug, const double *d_vg, const double *d_grid, int kcos,
+                                        double *pvor, double *pdiv, double *pspec, double *vor, double *div, double *t, double *tr,
+                                        double *ps, const double *phis, const double *d_tcorh, const double *d_qcorh, double sdrag,
+                                        int j1, double dt, double eps, double wil, double *phi);
 
 /* ---- multi-GPU: the one exchange a level-sharded step needs (one process per GPU, RCCL over xGMI) ------------
  * The transform batch shards over (field x level) with no communication.  implicit_terms couples all levels of a

@@ -60,6 +60,9 @@ SIGNATURES = {
     "spdy_hdiff_multi_dev": [c_void_p, c_int, c_void_p],
     "spdy_direct_batch_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "spdy_inverse_batch_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "spdy_direct_batch_spectral_step_dev": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double,
+                                            c_double, c_double, c_void_p],
     "spdy_inverse_batch_segs_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int, c_void_p, c_void_p, c_void_p, c_int],
     "spdy_inverse_batch_grad_dev": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,

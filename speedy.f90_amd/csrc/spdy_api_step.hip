@@ -270,9 +270,31 @@ int spdy_spectral_step_dev(spdy_plan *p, double *pvor, double *pdiv, double *psp
         return spdy_step_fields_dev(p, 5, ops, j1, dt, eps, wil);
     }
     const spdy::SpecStep a{pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, sdrag, dt, eps, wil, j1,
-                           p->tab.ix == 4 * p->tab.iy};
+                           p->tab.ix == 4 * p->tab.iy, nullptr, nullptr};
     KERNEL(spdy::launch_spectral_step(p->dev, a, p->stream));
     return SPDY_OK;
+}
+
+int spdy_direct_batch_spectral_step_dev(spdy_plan *p, const double *ug, const double *vg, const double *grid, int kcos, double *pvor,
+                                        double *pdiv, double *pspec, double *vor, double *div, double *t, double *tr, double *ps,
+                                        const double *phis, const double *d_tcorh, const double *d_qcorh, double sdrag, int j1, double dt,
+                                        double eps, double wil, double *phi)
+{
+    NEED_DEVICE(p);
+    const int kx = p->tab.kx, P = 3 * kx;
+    if (!ug || !vg || !grid || !pvor || !pdiv || !pspec) return fail(SPDY_ERR_ARG, "null device pointer");
+    if (p->tab.trunc == 63 && p->fused_mode != 0 && kx <= 16 && P <= p->max_batch && p->tab.implicit_ready && p->tab.sigma_ready && vor && div && t && tr &&
+        ps && phis && d_tcorh && d_qcorh && phi && (j1 == 1 || j1 == 2)) {
+        // T63: the transform kernel leaves the pairs' spectra un-vds'ed in the plan's temporaries; the spectral step applies
+        // vds where it reads them -- direct batch + everything after it = 2 launches instead of 3
+        RC(direct_batch_raw63(p, P, ug, vg, kcos, P + 1, grid, pspec));
+        const spdy::SpecStep a{pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, sdrag, dt, eps, wil, j1,
+                               p->tab.ix == 4 * p->tab.iy, p->tmp_c, p->tmp_d};
+        KERNEL(spdy::launch_spectral_step(p->dev, a, p->stream));
+        return SPDY_OK;
+    }
+    RC(spdy_direct_batch_dev(p, P, ug, vg, pvor, pdiv, kcos, P + 1, grid, pspec));
+    return spdy_spectral_step_dev(p, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, sdrag, j1, dt, eps, wil, phi);
 }
 
 /* ---------------------------------------------------------------- output path */

@@ -165,6 +165,9 @@ struct SpecStep {
     double *phi;
     double sdrag, dt, eps, wil;
     int j1, do_trunct;
+    // non-null: the vdspec pairs' spectra have NOT been through vds yet -- raw_u, raw_v [3kx] are grid_to_spec of the scaled
+    // (u, v) grids and the kernel applies vds (spectral.f90:146-171) where it reads them (pvor / pdiv are outputs only)
+    const double *raw_u, *raw_v;
 };
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s);
 // output path (input_output.f90:184-206)

@@ -58,6 +58,9 @@ int d2h(spdy_plan *p, double *dst, const double *src, size_t n);
 int sync(spdy_plan *p);
 int ensure_staging(spdy_plan *p);     // host-pointer entry points call this first
 int ensure_four(spdy_plan *p);        // four-kernel path workspace
+// T63 fused path: the direct batch WITHOUT vds -- the scaled (u, v) grids' spectra go to p->tmp_c / p->tmp_d, the plain
+// grids' to spec (spdy_direct_batch_spectral_step_dev)
+int direct_batch_raw63(spdy_plan *p, int npairs, const double *ug, const double *vg, int kcos, int nplain, const double *grid, double *spec);
 int upload_level_tables(spdy_plan *p);
 void release_comms(spdy_plan *p);     // plan teardown: RCCL communicators of this plan are shut down, their handles stay valid but dead
 

@@ -484,10 +484,41 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     auto put = [&](double *b, int kk, cpx z) { at(b, kk)[0] = z.re; at(b, kk)[1] = z.im; };
     STEP_MARK(0);
     // ---- tendency combination on the direct batch's outputs
-    cpx vordt = ld(a.pvor, i);
-    cpx divdt = ld(a.pdiv, i) - p.el2[ec] * (-ld(a.pspec, i));
-    cpx tdt = ld(a.pdiv, (long)kx * sz + i) + ld(a.pspec, (long)kx * sz + i);
-    cpx trdt = ld(a.pdiv, (long)2 * kx * sz + i) + ld(a.pspec, (long)2 * kx * sz + i);
+    cpx vordt, pd0, pd1, pd2;
+    if (a.raw_u) {
+        // vds of the three (u, v) pairs of this level where they are read (one launch less per step at T63, where the
+        // transform kernel does not apply it): the expressions of vds_kernel (spdy_kernels.hip), row by row.  Every load is
+        // unconditional at a clamped row; the rows the reference special-cases only choose among loaded values.
+        const int nm = max(n - 1, 0), np = min(n + 1, p.nx - 1);
+        const long rm = (long)k * sz + nm * p.mx + m, rp = (long)k * sz + np * p.mx + m, L = (long)kx * sz;
+        const double gx = p.gradx[m], dm = p.vddym[ec], dp = p.vddyp[ec];
+        const cpx u0 = ld(a.raw_u, i), u0m = ld(a.raw_u, rm), u0p = ld(a.raw_u, rp);
+        const cpx v0 = ld(a.raw_v, i), v0m = ld(a.raw_v, rm), v0p = ld(a.raw_v, rp);
+        const cpx u1 = ld(a.raw_u, L + i), v1m = ld(a.raw_v, L + rm), v1p = ld(a.raw_v, L + rp);
+        const cpx u2 = ld(a.raw_u, 2 * L + i), v2m = ld(a.raw_v, 2 * L + rm), v2p = ld(a.raw_v, 2 * L + rp);
+        auto vds_vor = [&](cpx um, cpx up, cpx v) {
+            if (n == 0) return times_i(gx * v) - dp * up;
+            if (n == p.nx - 1) return dm * um;
+            return (dm * um - dp * up) + times_i(gx * v);
+        };
+        auto vds_div = [&](cpx vm, cpx vp, cpx u) {
+            if (n == 0) return times_i(gx * u) + dp * vp;
+            if (n == p.nx - 1) return (-dm) * vm;
+            return ((-dm) * vm + dp * vp) + times_i(gx * u);
+        };
+        vordt = vds_vor(u0m, u0p, v0);
+        pd0 = vds_div(v0m, v0p, u0);
+        pd1 = vds_div(v1m, v1p, u1);
+        pd2 = vds_div(v2m, v2p, u2);
+    } else {
+        vordt = ld(a.pvor, i);
+        pd0 = ld(a.pdiv, i);
+        pd1 = ld(a.pdiv, (long)kx * sz + i);
+        pd2 = ld(a.pdiv, (long)2 * kx * sz + i);
+    }
+    cpx divdt = pd0 - p.el2[ec] * (-ld(a.pspec, i));
+    cpx tdt = pd1 + ld(a.pspec, (long)kx * sz + i);
+    cpx trdt = pd2 + ld(a.pspec, (long)2 * kx * sz + i);
     // ---- get_spectral_tendencies (time level 1 of div, t, ps).  Every thread brings its own level of div and t into LDS (one
     // coalesced global round trip for the block); the three level recurrences -- vertical mean, sigma-dot prefix sum, the
     // hydrostatic integration -- are then short loops over LDS by ONE wave each (k = 0 and k = 1 run them side by side),

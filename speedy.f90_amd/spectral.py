@@ -415,6 +415,16 @@ class Spectral:
         check(self.lib.spdy_spectral_step_dev(self.h, *[self._dp(x) for x in args], float(sdrag), int(j1), float(dt), float(eps),
                                               float(wil), self._dp(phi)))
 
+    def direct_batch_spectral_step_dev(self, ug, vg, grid, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, tcorh, qcorh, sdrag, j1, dt,
+                                       eps, wil, phi, kcos=2):
+        """direct_batch_dev(ug, vg [3kx] -> pvor, pdiv; grid [3kx+1] -> pspec) + spectral_step_dev as one call (at T63 vds is
+        applied where the spectral step reads the pairs' spectra: one launch less)."""
+        self._sync_stream()
+        args = (pvor, pdiv, pspec, vor, div, t, tr, ps, phis, tcorh, qcorh)
+        check(self.lib.spdy_direct_batch_spectral_step_dev(self.h, self._dp(ug), self._dp(vg), self._dp(grid), int(kcos),
+                                                           *[self._dp(x) for x in args], float(sdrag), int(j1), float(dt), float(eps),
+                                                           float(wil), self._dp(phi)))
+
     def output_batch_dev(self, vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out):
         """input_output.f90:184-206 on device-resident state: complex128 [kx,nx,mx] (ps [nx,mx]) in, float32 [kx,il,ix]
         (ps_out [il,ix]) out."""

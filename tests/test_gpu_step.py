@@ -323,8 +323,14 @@ def run_dynamical_core_steps(sp, o, tag, one_launch_tail, nsteps=2, collect=Fals
             sp.inverse_batch_segs_dev(D["vor"][1], D["div"][1], ug, vg, plain_src, plain_g, kcos_pairs=2, kcos=1)
             sp.grad_to_grid_dev(D["ps"][1:2], px, py, 2)
         sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
-        sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
-        if one_launch_tail:      # the five spectral-space kernels below as ONE launch (spdy_spectral_step_dev)
+        if one_launch_tail == "composite":   # direct batch + spectral step as one call (T63: vds applied on read, 5 launches)
+            sp.direct_batch_spectral_step_dev(U, V, PL, pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"],
+                                              D["tcorh"], D["qcorh"], SDRAG, 2, dt, ROB, WIL, phi, kcos=2)
+        else:
+            sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
+        if one_launch_tail == "composite":
+            pass
+        elif one_launch_tail:    # the five spectral-space kernels below as ONE launch (spdy_spectral_step_dev)
             sp.spectral_step_dev(pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"],
                                  SDRAG, 2, dt, ROB, WIL, phi)
         else:
@@ -343,7 +349,9 @@ def run_dynamical_core_steps(sp, o, tag, one_launch_tail, nsteps=2, collect=Fals
         for n, a in (("U", U), ("V", V), ("PL", PL)):
             e[n] = (synth.relerr(a.cpu().numpy(), out[n]),) * 2
         e["phi"] = (synth.relerr(phi.cpu().numpy(), out["phi"]), wave_relerr(phi.cpu().numpy(), out["phi"]))
-        if not one_launch_tail:
+        if one_launch_tail == "composite":
+            vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
+        if not one_launch_tail or one_launch_tail == "composite":
             # the tendencies the spectral side leaves behind (after implicit correction and diffusion): the quantity the
             # north star's 1e-12 names
             for n, a in (("vordt", vordt), ("divdt", divdt), ("tdt", tdt), ("trdt", trdt), ("psdt", psdt)):
@@ -355,7 +363,7 @@ def run_dynamical_core_steps(sp, o, tag, one_launch_tail, nsteps=2, collect=Fals
     return errs
 
 
-@pytest.mark.parametrize("one_launch_tail", [False, True])
+@pytest.mark.parametrize("one_launch_tail", [False, True, "composite"])
 @pytest.mark.parametrize("tag", ["t30", "t63k16", "t30k20"])
 def test_dynamical_core_step_graph(tag, one_launch_tail, oracle_factory):
     """SURVEY s8 f3 + f2: a COMPLETE adiabatic time step of the dynamical core on device-resident state, captured into one
