@@ -303,6 +303,7 @@ def extras(s, torch, synth, sp, dev, args):
     # the HOST-pointer drop-in as a Fortran host sees it (PCIe + syncs included; never `value`): the stock one-field-per-call
     # pattern of spectral.f90:98-122 and the level-stack extension, through the flang-built drop-in modules
     out["host_pointer_dropin"] = host_pointer_dropin()
+    out["fortran_step_loop"] = fortran_step_loop()
     return out
 
 
@@ -321,6 +322,26 @@ def host_pointer_dropin():
             res[tag] = {"per_field_calls_round_trips_per_s": float(f[0]), "level_stack_calls_round_trips_per_s": float(f[1]),
                         "fields_per_stack": int(f[3]),
                         "what": "Fortran host arrays -> drop-in spectral module -> C ABI (H2D, kernels, D2H, sync per call)"}
+        except Exception as e:
+            res[tag] = {"error": repr(e)}
+    return res
+
+
+def fortran_step_loop():
+    """Leapfrog steps per second of a flang-built main loop over the `time_stepping` drop-in (device-resident prognostics,
+    one captured graph per step; kx = 8, the reference's level count)."""
+    import subprocess
+    res = {}
+    for tag in ("t30", "t63"):
+        exe = os.path.join(ROOT, "speedy.f90_amd", "fortran", "build", tag, "dropin_step")
+        if not os.path.exists(exe):
+            res[tag] = {"error": "fortran/build/%s/dropin_step not built (flang absent at build time)" % tag}
+            continue
+        try:
+            o = subprocess.run([exe, "time", "2000"], capture_output=True, text=True, timeout=120, env=dict(os.environ, SPDY_DEVICE="0"))
+            f = o.stdout.split()
+            res[tag] = {"steps_per_s": float(f[0]), "us_per_step": round(1e6 / float(f[0]), 2), "steps": int(f[1]), "kx": int(f[3]),
+                        "what": "Fortran main loop: call step(2, 2, 2*delt) on device-resident prognostics (adiabatic core)"}
         except Exception as e:
             res[tag] = {"error": repr(e)}
     return res

@@ -26,6 +26,8 @@
 #ifndef SPDY_H
 #define SPDY_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -74,6 +76,16 @@ int spdy_plan_set_sigma(spdy_plan *plan, const double *hsg);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the plan's own. */
 int spdy_plan_set_stream(spdy_plan *plan, void *hip_stream);
 int spdy_plan_synchronize(spdy_plan *plan);
+/* Device memory for a host that has no HIP binding of its own (the Fortran model: fortran/time_stepping.f90 keeps the
+ * reference's prognostics -- prognostics.f90:16-24 -- in HBM with these).  spdy_dev_alloc returns zero-filled memory on
+ * the plan's device; upload/download are ordered on the plan's stream and return when the copy is complete; none of the
+ * four may be called while a graph capture is open (SPDY_ERR_STATE).  A host with HIP (hipfort, torch) does not need them:
+ * every *_dev entry point takes any device pointer.                                                                   */
+int spdy_dev_alloc(spdy_plan *plan, size_t bytes, void **d_ptr);
+int spdy_dev_free(spdy_plan *plan, void *d_ptr);
+int spdy_dev_upload(spdy_plan *plan, void *d_dst, const void *src, size_t bytes);
+int spdy_dev_download(spdy_plan *plan, void *dst, const void *d_src, size_t bytes);
+
 /* Per-kernel timing for the roofline report: while on, every transform kernel launched by the
  * *_dev entry points is bracketed by HIP events on its own stream.  spdy_plan_get_profile
  * synchronises, adds up milliseconds and launch counts per kernel kind (arrays of

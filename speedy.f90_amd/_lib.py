@@ -18,6 +18,10 @@ SIGNATURES = {
     "spdy_plan_destroy": [c_void_p],
     "spdy_plan_set_stream": [c_void_p, c_void_p],
     "spdy_plan_synchronize": [c_void_p],
+    "spdy_dev_alloc": [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)],
+    "spdy_dev_free": [c_void_p, c_void_p],
+    "spdy_dev_upload": [c_void_p, c_void_p, c_void_p, ctypes.c_size_t],
+    "spdy_dev_download": [c_void_p, c_void_p, c_void_p, ctypes.c_size_t],
     "spdy_plan_dims": [c_void_p, ctypes.POINTER(c_int)],
     "spdy_plan_set_profiling": [c_void_p, c_int],
     "spdy_plan_set_fused": [c_void_p, c_int],

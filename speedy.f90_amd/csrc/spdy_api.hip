@@ -538,6 +538,47 @@ int spdy_plan_synchronize(spdy_plan *p)
     return sync(p);
 }
 
+/* ---- device memory for hosts without a HIP binding of their own (a Fortran model: fortran/time_stepping.f90) ---- */
+int spdy_dev_alloc(spdy_plan *p, size_t bytes, void **d_ptr)
+{
+    NEED_DEVICE(p);
+    NOT_CAPTURING(p, "spdy_dev_alloc");
+    if (!d_ptr) return fail(SPDY_ERR_ARG, "null pointer");
+    *d_ptr = nullptr;
+    if (!bytes) return SPDY_OK;
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    HIP_TRY(hipMemsetAsync(*d_ptr, 0, bytes, p->stream));
+    return sync(p);
+}
+
+int spdy_dev_free(spdy_plan *p, void *d_ptr)
+{
+    NEED_DEVICE(p);
+    NOT_CAPTURING(p, "spdy_dev_free");
+    if (!d_ptr) return SPDY_OK;
+    RC(sync(p));                       // work queued on the plan's stream may still use it
+    HIP_TRY(hipFree(d_ptr));
+    return SPDY_OK;
+}
+
+int spdy_dev_upload(spdy_plan *p, void *d_dst, const void *src, size_t bytes)
+{
+    NEED_DEVICE(p);
+    NOT_CAPTURING(p, "spdy_dev_upload");
+    if (bytes && (!d_dst || !src)) return fail(SPDY_ERR_ARG, "null pointer");
+    if (bytes) HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+    return sync(p);
+}
+
+int spdy_dev_download(spdy_plan *p, void *dst, const void *d_src, size_t bytes)
+{
+    NEED_DEVICE(p);
+    NOT_CAPTURING(p, "spdy_dev_download");
+    if (bytes && (!dst || !d_src)) return fail(SPDY_ERR_ARG, "null pointer");
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, p->stream));
+    return sync(p);
+}
+
 int spdy_plan_set_profiling(spdy_plan *p, int on)
 {
     NEED_DEVICE(p);

@@ -6,6 +6,12 @@ module spdy_c
     implicit none
     public
 
+    !> spdy_spec_seg (include/spdy.h): one source array of plain spectra of spdy_inverse_batch_segs_dev
+    type, bind(C) :: spdy_spec_seg
+        integer(c_int) :: nb
+        type(c_ptr) :: d_spec
+    end type
+
     interface
         function spdy_plan_create(trunc, ix, iy, kx, max_batch, device, plan) bind(C, name="spdy_plan_create") result(rc)
             import :: c_int, c_ptr
@@ -205,6 +211,83 @@ module spdy_c
         function spdy_implicit_terms_sharded_dev(comm, divdt, tdt, psdt) bind(C, name="spdy_implicit_terms_sharded_dev") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: comm, divdt, tdt, psdt
+            integer(c_int) :: rc
+        end function
+        ! ---- device-resident state: memory, the step's entry points, graph capture (time_stepping.f90) ----------
+        function spdy_plan_synchronize(plan) bind(C, name="spdy_plan_synchronize") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int) :: rc
+        end function
+        function spdy_dev_alloc(plan, bytes, d_ptr) bind(C, name="spdy_dev_alloc") result(rc)
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), value :: plan
+            integer(c_size_t), value :: bytes
+            type(c_ptr), intent(out) :: d_ptr
+            integer(c_int) :: rc
+        end function
+        function spdy_dev_free(plan, d_ptr) bind(C, name="spdy_dev_free") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_ptr
+            integer(c_int) :: rc
+        end function
+        ! host side as type(*): any contiguous array (complex or real) goes up or comes down as bytes
+        function spdy_dev_upload(plan, d_dst, src, bytes) bind(C, name="spdy_dev_upload") result(rc)
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), value :: plan, d_dst
+            type(*), intent(in) :: src(*)
+            integer(c_size_t), value :: bytes
+            integer(c_int) :: rc
+        end function
+        function spdy_dev_download(plan, dst, d_src, bytes) bind(C, name="spdy_dev_download") result(rc)
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), value :: plan, d_src
+            type(*) :: dst(*)
+            integer(c_size_t), value :: bytes
+            integer(c_int) :: rc
+        end function
+        function spdy_graph_begin(plan) bind(C, name="spdy_graph_begin") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int) :: rc
+        end function
+        function spdy_graph_end(plan, graph) bind(C, name="spdy_graph_end") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            type(c_ptr), intent(out) :: graph
+            integer(c_int) :: rc
+        end function
+        function spdy_graph_launch(graph) bind(C, name="spdy_graph_launch") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: graph
+            integer(c_int) :: rc
+        end function
+        function spdy_graph_destroy(graph) bind(C, name="spdy_graph_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: graph
+            integer(c_int) :: rc
+        end function
+        ! every array argument below is a device pointer
+        function spdy_inverse_batch_segs_dev(plan, npairs, d_vor, d_div, d_ug, d_vg, kcos_pairs, nseg, segs, d_kcos, kcos_all, &
+                & d_grid, ngrad, d_psi, d_gx, d_gy, kcos_grad) bind(C, name="spdy_inverse_batch_segs_dev") result(rc)
+            import :: c_int, c_ptr, spdy_spec_seg
+            type(c_ptr), value :: plan, d_vor, d_div, d_ug, d_vg, d_kcos, d_grid, d_psi, d_gx, d_gy
+            integer(c_int), value :: npairs, kcos_pairs, nseg, kcos_all, ngrad, kcos_grad
+            type(spdy_spec_seg), intent(in) :: segs(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_grid_tendencies_dev(plan, ug, vg, tg, vorg, divg, trg, px, py, u_out, v_out, plain_out) &
+                & bind(C, name="spdy_grid_tendencies_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, ug, vg, tg, vorg, divg, trg, px, py, u_out, v_out, plain_out
+            integer(c_int) :: rc
+        end function
+        function spdy_direct_batch_spectral_step_dev(plan, d_ug, d_vg, d_grid, kcos, pvor, pdiv, pspec, vor, div, t, tr, ps, &
+                & phis, d_tcorh, d_qcorh, sdrag, j1, dt, eps, wil, phi) bind(C, name="spdy_direct_batch_spectral_step_dev") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: plan, d_ug, d_vg, d_grid, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi
+            integer(c_int), value :: kcos, j1
+            real(c_double), value :: sdrag, dt, eps, wil
             integer(c_int) :: rc
         end function
     end interface

@@ -1,0 +1,79 @@
+!> Test driver for the `time_stepping` drop-in: reads a seeded model state written by tests/test_fortran_dropin.py, runs
+!  the model's own start-up sequence (first_step) and `nleap` leapfrog steps exactly as the model's main loop would
+!  (speedy.f90: call step(2, 2, 2*delt)), and writes the state after every step for the test to compare with the reference sequence.
+program dropin_step
+    use types, only: p
+    use params
+    use spectral, only: initialize_spectral, finalize_spectral
+    use horizontal_diffusion, only: initialize_horizontal_diffusion, tcorh, qcorh
+    use geopotential, only: initialize_geopotential
+    use prognostics
+    use time_stepping
+    implicit none
+    complex(p) :: vordt(mx,nx,kx), divdt(mx,nx,kx), tdt(mx,nx,kx), psdt(mx,nx), trdt(mx,nx,kx,ntr)
+    integer :: nleap, i
+    integer(8) :: c0, c1, cr
+    logical :: return_now = .false.
+    character(len=512) :: fin, fout, arg
+
+    call get_command_argument(1, fin)
+    if (trim(fin) == 'time') then        ! dropin_step time <nsteps>: leapfrog steps per second of this main loop
+        call get_command_argument(2, arg)
+        read (arg, *) nleap
+        call isothermal_state
+        call initialize_spectral
+        call initialize_geopotential
+        call initialize_horizontal_diffusion
+        call first_step
+        do i = 1, 20
+            call step(2, 2, 2*delt)
+        end do
+        call prognostics_from_device
+        call system_clock(c0, cr)
+        do i = 1, nleap
+            call step(2, 2, 2*delt)
+        end do
+        call prognostics_from_device     ! waits for the queued steps (and brings the state back, as an output step would)
+        call system_clock(c1)
+        if (any(t /= t)) error stop 'dropin_step: the state did not stay finite'
+        write (*, '(F12.2,I8,3I5)') real(nleap, 8)*real(cr, 8)/real(c1 - c0, 8), nleap, trunc, kx, ntr
+        call finalize_time_stepping
+        call finalize_spectral
+        return_now = .true.
+    end if
+    if (return_now) goto 99
+    call get_command_argument(2, fout)
+    call get_command_argument(3, arg)
+    read (arg, *) nleap
+    open(10, file=trim(fin), access='stream', form='unformatted', status='old')
+    read(10) vor, div, t, tr, ps, phis, tcorh, qcorh
+    close(10)
+
+    call initialize_spectral
+    call initialize_geopotential
+    call initialize_horizontal_diffusion
+    open(11, file=trim(fout), access='stream', form='unformatted', status='replace')
+    call first_step                      ! forward half step, first leapfrog step (both written below as one record)
+    call dump
+    do i = 1, nleap
+        call step(2, 2, 2*delt)
+        call dump
+    end do
+    close(11)
+    call finalize_time_stepping
+    call finalize_spectral
+99  continue
+contains
+    !> an isothermal atmosphere at rest over a flat surface: stays finite for any step count and step length (the step's
+    !  cost does not depend on the values)
+    subroutine isothermal_state
+        vor = 0; div = 0; t = 0; tr = 0; ps = 0; phis = 0; tcorh = 0; qcorh = 0
+        t(1,1,:,:) = 250.0_p*sqrt(2.0_p)
+    end subroutine
+
+    subroutine dump
+        call prognostics_from_device
+        call tendencies_from_device(vordt, divdt, tdt, psdt, trdt)
+        write(11) vor, div, t, tr, ps, phi, vordt, divdt, tdt, trdt, psdt
+    end subroutine
+end program

@@ -9,6 +9,7 @@ module types
 end module
 
 module params
+    use iso_fortran_env, only: real64
     implicit none
 #ifdef SPDY_T63
     integer, parameter :: trunc = 63, ix = 192, iy = 48
@@ -17,4 +18,7 @@ module params
 #endif
     integer, parameter :: il = 2*iy, kx = 8, nx = trunc + 2, mx = trunc + 1
     integer, parameter :: nsteps = 36          ! params.f90:30 (read by initialize_horizontal_diffusion)
+    ! read by time_stepping (params.f90:26, :31-33); default-real literals, as the model writes them
+    integer, parameter :: ntr = 1
+    real(real64), parameter :: delt = real(86400.0/nsteps, real64), rob = real(0.05, real64), wil = real(0.53, real64)
 end module

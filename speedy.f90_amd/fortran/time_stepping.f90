@@ -1,0 +1,213 @@
+!> Drop-in replacement for the reference's `time_stepping` module (source/time_stepping.f90): same module name and the
+!  same public subroutines, first_step and step(j1, j2, dt), for the ADIABATIC dynamical core -- everything step() does
+!  except get_physical_tendencies (column physics, outside this library's scope, SURVEY s8).
+!
+!  The reference's step() (time_stepping.f90:35-118) walks the host arrays of `prognostics` through get_tendencies
+!  (tendencies.f90:11-41: 6 kx + 2 inverse and 9 kx + 1 direct transforms, the grid-space tendencies, the spectral
+!  tendencies, the implicit correction), the diffusion block and step_field_2d/3d.  Here the prognostics live in HBM and
+!  the whole step is three calls on device pointers,
+!      spdy_inverse_batch_segs_dev          everything that goes to the grid           tendencies.f90:89-107, :121-123
+!      spdy_grid_tendencies_dev             the grid-space dynamical tendencies        tendencies.f90:105-197
+!      spdy_direct_batch_spectral_step_dev  direct transforms and all the rest         tendencies.f90:212-293, implicit.f90:168-217,
+!                                                                                      time_stepping.f90:62-167
+!  captured into one graph for the leapfrog step (j1 = j2 = 2) and replayed: 4 kernel launches at T30, 5 at T63, no host
+!  arithmetic, no PCIe traffic.  Results agree with the reference's call-by-call sequence to 1e-12
+!  (tests/test_fortran_dropin.py, the time_stepping case).
+!
+!  The host arrays of `prognostics` are uploaded at the first step (or by prognostics_to_device, after the model changed
+!  them) and are NOT kept current: call prognostics_from_device before reading vor, div, t, ps, tr, phi on the host
+!  (output, diagnostics, restart files).  tcorh/qcorh (horizontal_diffusion, filled by forcing.f90) and phis travel with
+!  prognostics_to_device.
+module time_stepping
+    use iso_c_binding
+    use types, only: p
+    use params
+    use spdy_c
+    use spectral, only: spectral_plan, initialize_spectral
+
+    implicit none
+
+    private
+    public first_step, step
+    ! extensions (not in the reference)
+    public prognostics_to_device, prognostics_from_device, tendencies_from_device, finalize_time_stepping
+
+    integer(c_size_t), parameter :: spec_bytes = 16_c_size_t*mx*nx, grid_bytes = 8_c_size_t*ix*il
+
+    logical :: resident = .false.
+    ! model state: vor, div, t, tr (mx,nx,kx,2); ps (mx,nx,2); phi (mx,nx,kx); phis, tcorh, qcorh (mx,nx)
+    type(c_ptr) :: d_vor = c_null_ptr, d_div = c_null_ptr, d_t = c_null_ptr, d_tr = c_null_ptr, d_ps = c_null_ptr
+    type(c_ptr) :: d_phi = c_null_ptr, d_phis = c_null_ptr, d_tcorh = c_null_ptr, d_qcorh = c_null_ptr
+    ! one step's intermediates: grids of time level j2 (ug, vg [kx]; vorg | divg | tg | trg [4 kx]; px, py), the grid
+    ! tendencies as operands of the direct batch (U, V [3 kx]; PL [3 kx + 1]) and their spectra / the spectral tendencies
+    type(c_ptr) :: d_ug = c_null_ptr, d_vg = c_null_ptr, d_plain = c_null_ptr, d_px = c_null_ptr, d_py = c_null_ptr
+    type(c_ptr) :: d_u = c_null_ptr, d_v = c_null_ptr, d_pl = c_null_ptr
+    type(c_ptr) :: d_pvor = c_null_ptr, d_pdiv = c_null_ptr, d_pspec = c_null_ptr
+    ! the captured leapfrog step and what it was captured for
+    type(c_ptr) :: graph = c_null_ptr
+    integer :: graph_j1 = 0, graph_j2 = 0
+    real(p) :: graph_dt = 0
+
+contains
+    !> time_stepping.f90:11-24
+    subroutine first_step
+        use implicit, only: initialize_implicit
+
+        call initialize_implicit(0.5*delt)
+
+        call step(1, 1, 0.5*delt)
+
+        call initialize_implicit(delt)
+
+        call step(1, 2, delt)
+
+        call initialize_implicit(2*delt)
+    end subroutine
+
+    !> time_stepping.f90:35-118 without the physics: Fnew = F(1) + dt * T_dyn(F(j2)); F(1) = (1-2 eps) F(j1) + eps (F(1) + Fnew)
+    !  (with the Williams correction of :159-163); F(2) = Fnew.  j1 == 1: eps = 0; j1 == 2: eps = rob.
+    subroutine step(j1, j2, dt)
+        integer, intent(in) :: j1, j2
+        real(p), intent(in) :: dt
+        real(p) :: eps
+
+        if (j1 < 1 .or. j1 > 2 .or. j2 < 1 .or. j2 > 2) error stop 'time_stepping%step: j1, j2 must be 1 or 2'
+        if (.not. resident) call prognostics_to_device
+        if (j1 == 1) then
+            eps = 0.0
+        else
+            eps = rob
+        end if
+
+        if (j1 /= 2) then                 ! the two start-up steps run once: plain launches
+            call enqueue_step(j1, j2, dt, eps)
+            return
+        end if
+        if (c_associated(graph) .and. (graph_j1 /= j1 .or. graph_j2 /= j2 .or. graph_dt /= dt)) then
+            call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
+            graph = c_null_ptr
+        end if
+        if (.not. c_associated(graph)) then
+            ! The implicit and damping tables are refreshed in place by initialize_implicit: the captured step sees them.
+            call spdy_check(spdy_graph_begin(spectral_plan), 'graph_begin')
+            call enqueue_step(j1, j2, dt, eps)
+            call spdy_check(spdy_graph_end(spectral_plan, graph), 'graph_end')
+            graph_j1 = j1; graph_j2 = j2; graph_dt = dt
+        end if
+        call spdy_check(spdy_graph_launch(graph), 'graph_launch')
+    end subroutine
+
+    !> One adiabatic step on the plan's stream (returns when it is queued).
+    subroutine enqueue_step(j1, j2, dt, eps)
+        use dynamical_constants, only: tdrs
+        integer, intent(in) :: j1, j2
+        real(p), intent(in) :: dt, eps
+        type(spdy_spec_seg) :: segs(4)
+        real(p) :: sdrag
+        integer(c_size_t) :: lev3, lev2
+
+        lev3 = (j2 - 1)*kx*spec_bytes            ! time level j2 of an (mx,nx,kx,2) array
+        lev2 = (j2 - 1)*spec_bytes               ! ... of ps
+        segs(1) = spdy_spec_seg(int(kx, c_int), at(d_vor, lev3))
+        segs(2) = spdy_spec_seg(int(kx, c_int), at(d_div, lev3))
+        segs(3) = spdy_spec_seg(int(kx, c_int), at(d_t, lev3))
+        segs(4) = spdy_spec_seg(int(kx, c_int), at(d_tr, lev3))
+        ! tendencies.f90:89-107, :121-123: u, v (kcos = 2) from vor, div; vorg, divg, tg, trg (kcos = 1); grad(ps) (kcos = 2)
+        call spdy_check(spdy_inverse_batch_segs_dev(spectral_plan, int(kx, c_int), at(d_vor, lev3), at(d_div, lev3), d_ug, d_vg, &
+            & 2_c_int, 4_c_int, segs, c_null_ptr, 1_c_int, d_plain, 1_c_int, at(d_ps, lev2), d_px, d_py, 2_c_int), &
+            & 'inverse_batch_segs_dev')
+        call spdy_check(spdy_grid_tendencies_dev(spectral_plan, d_ug, d_vg, at(d_plain, 2*kx*grid_bytes), d_plain, &
+            & at(d_plain, kx*grid_bytes), at(d_plain, 3*kx*grid_bytes), d_px, d_py, d_u, d_v, d_pl), 'grid_tendencies_dev')
+        sdrag = 1.0/(tdrs*3600.0)                ! time_stepping.f90:77
+        call spdy_check(spdy_direct_batch_spectral_step_dev(spectral_plan, d_u, d_v, d_pl, 2_c_int, d_pvor, d_pdiv, d_pspec, &
+            & d_vor, d_div, d_t, d_tr, d_ps, d_phis, d_tcorh, d_qcorh, sdrag, int(j1, c_int), dt, eps, wil, d_phi), &
+            & 'direct_batch_spectral_step_dev')
+    end subroutine
+
+    !> Host arrays of `prognostics` (and phis, tcorh, qcorh) -> HBM; allocates the device state on first use.
+    subroutine prognostics_to_device
+        use prognostics, only: vor, div, t, ps, tr, phis
+        use horizontal_diffusion, only: tcorh, qcorh
+
+        if (ntr /= 1) error stop 'time_stepping: the device step carries one tracer (ntr = 1, params.f90:26)'
+        call initialize_spectral
+        if (.not. c_associated(d_vor)) then
+            call alloc(d_vor, 2*kx*spec_bytes); call alloc(d_div, 2*kx*spec_bytes); call alloc(d_t, 2*kx*spec_bytes)
+            call alloc(d_tr, 2*kx*spec_bytes);  call alloc(d_ps, 2*spec_bytes);     call alloc(d_phi, kx*spec_bytes)
+            call alloc(d_phis, spec_bytes);     call alloc(d_tcorh, spec_bytes);    call alloc(d_qcorh, spec_bytes)
+            call alloc(d_ug, kx*grid_bytes);    call alloc(d_vg, kx*grid_bytes);    call alloc(d_plain, 4*kx*grid_bytes)
+            call alloc(d_px, grid_bytes);       call alloc(d_py, grid_bytes)
+            call alloc(d_u, 3*kx*grid_bytes);   call alloc(d_v, 3*kx*grid_bytes);   call alloc(d_pl, (3*kx + 1)*grid_bytes)
+            call alloc(d_pvor, 3*kx*spec_bytes); call alloc(d_pdiv, 3*kx*spec_bytes); call alloc(d_pspec, (3*kx + 1)*spec_bytes)
+        end if
+        call spdy_check(spdy_dev_upload(spectral_plan, d_vor, vor, 2*kx*spec_bytes), 'upload vor')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_div, div, 2*kx*spec_bytes), 'upload div')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_t, t, 2*kx*spec_bytes), 'upload t')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_tr, tr, 2*kx*spec_bytes), 'upload tr')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_ps, ps, 2*spec_bytes), 'upload ps')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_phis, phis, spec_bytes), 'upload phis')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_tcorh, tcorh, spec_bytes), 'upload tcorh')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_qcorh, qcorh, spec_bytes), 'upload qcorh')
+        resident = .true.
+    end subroutine
+
+    !> HBM -> host arrays of `prognostics` (both time levels) and the geopotential of the last step; waits for the steps
+    !  queued so far.
+    subroutine prognostics_from_device
+        use prognostics, only: vor, div, t, ps, tr, phi
+
+        if (.not. resident) return
+        call spdy_check(spdy_dev_download(spectral_plan, vor, d_vor, 2*kx*spec_bytes), 'download vor')
+        call spdy_check(spdy_dev_download(spectral_plan, div, d_div, 2*kx*spec_bytes), 'download div')
+        call spdy_check(spdy_dev_download(spectral_plan, t, d_t, 2*kx*spec_bytes), 'download t')
+        call spdy_check(spdy_dev_download(spectral_plan, tr, d_tr, 2*kx*spec_bytes), 'download tr')
+        call spdy_check(spdy_dev_download(spectral_plan, ps, d_ps, 2*spec_bytes), 'download ps')
+        call spdy_check(spdy_dev_download(spectral_plan, phi, d_phi, kx*spec_bytes), 'download phi')
+    end subroutine
+
+    !> The tendencies the last step applied -- after the implicit correction and the diffusion, truncated as step_field_2d
+    !  leaves them (time_stepping.f90:155-157): the local arrays of the reference's step().
+    subroutine tendencies_from_device(vordt, divdt, tdt, psdt, trdt)
+        complex(p), dimension(mx,nx,kx), intent(out) :: vordt, divdt, tdt
+        complex(p), intent(out) :: psdt(mx,nx), trdt(mx,nx,kx,ntr)
+
+        if (.not. resident) error stop 'time_stepping%tendencies_from_device before the first step'
+        ! pvor = vordt | .. ; pdiv = divdt | tdt | trdt ; pspec(3 kx + 1) = psdt  (include/spdy.h, spdy_grid_tendencies_dev)
+        call spdy_check(spdy_dev_download(spectral_plan, vordt, d_pvor, kx*spec_bytes), 'download vordt')
+        call spdy_check(spdy_dev_download(spectral_plan, divdt, d_pdiv, kx*spec_bytes), 'download divdt')
+        call spdy_check(spdy_dev_download(spectral_plan, tdt, at(d_pdiv, kx*spec_bytes), kx*spec_bytes), 'download tdt')
+        call spdy_check(spdy_dev_download(spectral_plan, trdt, at(d_pdiv, 2*kx*spec_bytes), kx*spec_bytes), 'download trdt')
+        call spdy_check(spdy_dev_download(spectral_plan, psdt, at(d_pspec, 3*kx*spec_bytes), spec_bytes), 'download psdt')
+    end subroutine
+
+    !> Releases the captured step and the device state (before spectral%finalize_spectral).
+    subroutine finalize_time_stepping
+        if (c_associated(graph)) call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
+        graph = c_null_ptr
+        call release(d_vor); call release(d_div); call release(d_t); call release(d_tr); call release(d_ps); call release(d_phi)
+        call release(d_phis); call release(d_tcorh); call release(d_qcorh)
+        call release(d_ug); call release(d_vg); call release(d_plain); call release(d_px); call release(d_py)
+        call release(d_u); call release(d_v); call release(d_pl); call release(d_pvor); call release(d_pdiv); call release(d_pspec)
+        resident = .false.
+    end subroutine
+
+    subroutine alloc(ptr, bytes)
+        type(c_ptr), intent(out) :: ptr
+        integer(c_size_t), intent(in) :: bytes
+        call spdy_check(spdy_dev_alloc(spectral_plan, bytes, ptr), 'dev_alloc')
+    end subroutine
+
+    subroutine release(ptr)
+        type(c_ptr), intent(inout) :: ptr
+        if (c_associated(ptr)) call spdy_check(spdy_dev_free(spectral_plan, ptr), 'dev_free')
+        ptr = c_null_ptr
+    end subroutine
+
+    !> device address `base + bytes`
+    pure function at(base, bytes) result(ptr)
+        type(c_ptr), intent(in) :: base
+        integer(c_size_t), intent(in) :: bytes
+        type(c_ptr) :: ptr
+        ptr = transfer(transfer(base, 0_c_intptr_t) + int(bytes, c_intptr_t), ptr)
+    end function
+end module

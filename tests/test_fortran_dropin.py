@@ -40,6 +40,13 @@ def test_fortran_sources_keep_reference_api():
         pub = " ".join(l for l in head.split("\n") if l.strip().startswith("public"))
         for name in names:
             assert name in pub, (mod, name)
+    # the caller side: time_stepping keeps first_step and step(j1, j2, dt) (time_stepping.f90:8, :35)
+    src = open(os.path.join(FDIR, "time_stepping.f90")).read().lower()
+    assert "module time_stepping" in src and "public first_step, step" in src
+    assert "subroutine step(j1, j2, dt)" in src and "subroutine first_step" in src
+    for name in ("spdy_dev_alloc", "spdy_graph_begin", "spdy_inverse_batch_segs_dev", "spdy_grid_tendencies_dev",
+                 "spdy_direct_batch_spectral_step_dev"):
+        assert 'name="%s"' % name in open(os.path.join(FDIR, "spdy_c.f90")).read(), name
 
 
 def test_reference_callers_resolve_against_dropins():
@@ -64,6 +71,8 @@ def test_driver_fails_loudly_without_gpu(tag):
         pytest.skip("Fortran driver not built (no flang)")
     r = subprocess.run([driver(tag), "/dev/null", "/dev/null"], capture_output=True, text=True)
     assert r.returncode != 0                          # no device -> error stop, never a silent CPU path
+    r = subprocess.run([os.path.join(FDIR, "build", tag, "dropin_step"), "time", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "spdy" in (r.stdout + r.stderr).lower()
 
 
 @pytest.mark.gpu
@@ -139,3 +148,57 @@ def test_dropin_module_vs_oracle(tag, tmp_path, oracle_factory):
         a, b = o.vdspec(gx[k], gy[k], 2)
         ok(vorl[k], a); ok(divl[k], b)
     assert pos[0] == raw.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["t30", "t63"])
+def test_time_stepping_dropin_vs_oracle(tag, tmp_path, oracle_factory):
+    """The `time_stepping` drop-in (fortran/time_stepping.f90): a flang-built main loop calls first_step and step(2, 2, 2*delt)
+    as the model does (time_stepping.f90:11-24, :35-118 without the column physics); the prognostics stay in HBM, the leapfrog
+    step is one captured graph.  After the start-up sequence and after each leapfrog step: both time levels of the five
+    prognostics, the geopotential and the tendencies the step applied, against the oracle's call-by-call sequence at 1e-12
+    of each array's maximum, in the plain norm and with the global mean removed."""
+    from test_gpu_step import ROB, WIL, state, oracle_dynamics_step, wave_relerr
+    exe = os.path.join(FDIR, "build", tag, "dropin_step")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built (no flang on this box and no prebuilt binary)")
+    o = oracle_factory(tag)
+    nx, mx, kx = o.nx, o.mx, o.kx
+    st = state(o, 8000)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        for n in ("vor", "div", "t", "tr", "ps", "phis", "tcorh", "qcorh"):
+            f.write(np.ascontiguousarray(st[n]).tobytes())
+    nleap = 2
+    r = subprocess.run([exe, str(fin), str(fout), str(nleap)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(fout, np.float64).view(np.complex128)
+    pos = [0]
+
+    def take(*shape):
+        n = int(np.prod(shape))
+        a = raw[pos[0]:pos[0] + n]
+        pos[0] += n
+        return a.reshape(shape)
+
+    delt = float(np.float32(86400.0) / np.float32(36))               # params.f90:31
+    # first_step (time_stepping.f90:11-24): forward half step from level 1, leapfrog step without filter, then 2*delt
+    o.tail_init(0.5 * delt); ref, _ = oracle_dynamics_step(o, st, 1, 0.5 * delt, 0.0, j2=1)
+    o.tail_init(delt); ref, out = oracle_dynamics_step(o, ref, 1, delt, 0.0, j2=2)
+    o.tail_init(2 * delt)
+    worst = {}
+    for rec in range(1 + nleap):
+        if rec:
+            ref, out = oracle_dynamics_step(o, ref, 2, 2 * delt, ROB, j2=2)
+        got = {n: take(2, kx, nx, mx) for n in ("vor", "div", "t", "tr")}
+        got["ps"], got["phi"] = take(2, nx, mx), take(kx, nx, mx)
+        for n in ("vordt", "divdt", "tdt", "trdt"):
+            got[n] = take(kx, nx, mx)
+        got["psdt"] = take(nx, mx)
+        for n, a in got.items():
+            want = ref[n] if n in ref and n != "phi" else out[n]
+            e = max(synth.relerr(a, want), wave_relerr(a, want))
+            worst[n] = max(worst.get(n, 0.0), e)
+            assert e <= TOL, (tag, rec, n, e)
+    assert pos[0] == raw.size
+    print("\n[time_stepping drop-in %s] worst relative errors: " % tag + " ".join("%s %.1e" % kv for kv in worst.items()))

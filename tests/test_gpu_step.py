@@ -252,11 +252,11 @@ def test_output_path(tag, oracle_factory):
     g.close(); sp.close()
 
 
-def oracle_dynamics_step(o, st, j1, dt, eps):
+def oracle_dynamics_step(o, st, j1, dt, eps, j2=2):
     """One adiabatic time step of the dynamical core on the host, the reference's own call sequence (tendencies.f90:11-41,
-    time_stepping.f90:35-118 without get_physical_tendencies): inverse transforms of time level j2 = 2, grid-space
+    time_stepping.f90:35-118 without get_physical_tendencies): inverse transforms of time level j2, grid-space
     tendencies, direct transforms, spectral tendencies, implicit correction, diffusion, leapfrog/RAW."""
-    kx, j2 = o.kx, 1
+    kx, j2 = o.kx, j2 - 1
     ug, vg = [], []
     for k in range(kx):
         u, v = o.uvspec(st["vor"][j2, k], st["div"][j2, k])
