@@ -84,8 +84,8 @@ __global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *_
 
 static size_t implicit_lds(int kx) { return (size_t)3 * kx * 64 * 16; }
 
-size_t spectral_step_lds(int kx);
-size_t grid_tendencies_lds(int kx);
+size_t spectral_step_lds(int kx, int bx = 16);
+size_t grid_tendencies_lds(int kx, int bx = 16);
 __global__ void grid_tendencies_kernel(DevPlan p, GridTend g);
 __global__ void spectral_step_kernel(DevPlan p, SpecStep a);
 __global__ void spectral_step_kernel16(DevPlan p, SpecStep a);
@@ -346,7 +346,7 @@ __global__ void grid_tendencies_serial_kernel(DevPlan p, GridTend g)
 #undef LV
 }
 
-// Block = 64 grid points x kx level rows (one wave per level): every thread fetches its own level of the six fields at once
+// Block = BX (16) grid points x kx level rows: every thread fetches its own level of the six fields at once
 // (one coalesced memory round trip for the block instead of one per level of a serial per-point loop: 24 -> see DESIGN at
 // T63 L16); the vertical means and the sigma-dot prefix sums are short loops over LDS by wave 0, everything else is per
 // (point, level) with the neighbouring levels read from LDS.  Expressions as in the reference's loops.
@@ -354,14 +354,15 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int gsz = p.ix * p.il, kx = p.kx, tx = threadIdx.x, k = threadIdx.y;
-    const int i0 = blockIdx.x * 64 + tx;
+    const int BX = blockDim.x;                                             // grid points per block
+    const int i0 = blockIdx.x * BX + tx;
     const bool valid = i0 < gsz;
     const int i = valid ? i0 : gsz - 1, j = i / p.ix;
-    double *su = sm, *sv = sm + kx * 64, *st = sm + 2 * kx * 64, *sq = sm + 3 * kx * 64, *sp = sm + 4 * kx * 64, *sd = sm + 5 * kx * 64;
-    double *ssig = sm + 6 * kx * 64, *ssigm = ssig + (kx + 1) * 64, *smean = ssigm + (kx + 1) * 64;   // smean: umean, vmean, dmean rows
-    double *stab = smean + 3 * 64;                                                                    // dhs[kx]
+    double *su = sm, *sv = sm + kx * BX, *st = sm + 2 * kx * BX, *sq = sm + 3 * kx * BX, *sp = sm + 4 * kx * BX, *sd = sm + 5 * kx * BX;
+    double *ssig = sm + 6 * kx * BX, *ssigm = ssig + (kx + 1) * BX, *smean = ssigm + (kx + 1) * BX;   // smean: umean, vmean, dmean rows
+    double *stab = smean + 3 * BX;                                                                    // dhs[kx]
 #define LV(a_, k_) (a_)[(long)(k_) * gsz + i]
-#define S(b_, k_) (b_)[(k_) * 64 + tx]
+#define S(b_, k_) (b_)[(k_) * BX + tx]
     const double ug_c = LV(g.ug, k), vg_c = LV(g.vg, k), tg_c = LV(g.tg, k), tr_c = LV(g.trg, k), dv = LV(g.divg, k);
     const double vor = LV(g.vorg, k) + p.coriol[j];                                        // (:103-107 coriolis)
     const double px = g.px[i], py = g.py[i], rgas = p.rgas, akap = p.akap;
@@ -378,10 +379,10 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
             vmean = vmean + S(sv, kk) * dh;
             dmean = dmean + S(sd, kk) * dh;
         }
-        smean[tx] = umean; smean[64 + tx] = vmean; smean[128 + tx] = dmean;
+        smean[tx] = umean; smean[BX + tx] = vmean; smean[2 * BX + tx] = dmean;
     }
     lds_sync();
-    const double umean = smean[tx], vmean = smean[64 + tx], dmean = smean[128 + tx];
+    const double umean = smean[tx], vmean = smean[BX + tx], dmean = smean[2 * BX + tx];
     const double puv = (ug_c - umean) * px + (vg_c - vmean) * py;                          // (:136)
     S(sp, k) = puv;
     lds_sync();
@@ -427,13 +428,18 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
 #undef S
 }
 
-size_t grid_tendencies_lds(int kx) { return ((size_t)(6 * kx + 2 * (kx + 1) + 3) * 64 + kx) * sizeof(double); }
+size_t grid_tendencies_lds(int kx, int bx) { return ((size_t)(6 * kx + 2 * (kx + 1) + 3) * bx + kx) * sizeof(double); }
 
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s)
 {
     const int gsz = p.ix * p.il;
     if (p.kx > 16) hipLaunchKernelGGL(grid_tendencies_serial_kernel, dim3((gsz + 63) / 64), dim3(64), 0, s, p, g);
-    else hipLaunchKernelGGL(grid_tendencies_kernel, dim3((gsz + 63) / 64), dim3(64, p.kx), grid_tendencies_lds(p.kx), s, p, g);
+    else {
+        // 16 points x kx levels per block: at model sizes the kernel is a latency chain per block, and 4x as many (smaller)
+        // blocks spread its LDS traffic and loads over 4x as many CUs (T30: 72 -> 288 blocks; T63 L16 step 92.3 -> 89.2 us)
+        const int bx = 16;
+        hipLaunchKernelGGL(grid_tendencies_kernel, dim3((gsz + bx - 1) / bx), dim3(bx, p.kx), grid_tendencies_lds(p.kx, bx), s, p, g);
+    }
     return hipGetLastError();
 }
 
@@ -462,7 +468,7 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // The whole spectral-space tail of a time step in ONE launch: tendency combination (tendencies.f90:125-126, 218-233),
 // get_spectral_tendencies (:242-293), implicit_terms (implicit.f90:168-217), the diffusion block and step_field_*
 // (time_stepping.f90:62-167).  At model sizes each of the five kernels above is a ~6 us launch around a few hundred KB;
-// fused, the tendencies never leave the CU between them.  Block = 64 coefficients x kx level rows (kx <= 16): thread
+// fused, the tendencies never leave the CU between them.  Block = BX (16) coefficients x kx level rows (kx <= 16): thread
 // (e, k) owns the tendencies of one coefficient at one level in registers; the level-coupled parts (vertical sums,
 // geopotential recursion, the kx x kx mat-vecs) go through LDS.  Every expression is the one of the separate kernel, so
 // the results are bit-identical to the unfused sequence.
@@ -474,12 +480,14 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];           // complex planes [kx][64]: divdt, tdt, phi / yf / d, div, t; + rows
     const int kx = p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
-    const int e = blockIdx.x * 64 + tx;
+    const int BX = blockDim.x;                                             // coefficients per block (16, 32 or 64)
+    const int e = blockIdx.x * BX + tx;
     const bool valid = e < sz;
     const int ec = valid ? e : sz - 1, m = ec % p.mx, n = ec / p.mx, l = m + n;
     const long i = (long)k * sz + ec;                                     // this thread's (level, coefficient)
-    double *sdiv = sm, *stdt = sm + (size_t)kx * 128, *sy = sm + (size_t)kx * 256;
-    auto at = [&](double *b, int kk) { return b + ((size_t)kk * 64 + tx) * 2; };
+    const size_t PL = (size_t)kx * 2 * BX;                                 // doubles per complex plane [kx][BX]
+    double *sdiv = sm, *stdt = sm + PL, *sy = sm + 2 * PL;
+    auto at = [&](double *b, int kk) { return b + ((size_t)kk * BX + tx) * 2; };
     auto get = [&](double *b, int kk) { return cpx{at(b, kk)[0], at(b, kk)[1]}; };
     auto put = [&](double *b, int kk, cpx z) { at(b, kk)[0] = z.re; at(b, kk)[1] = z.im; };
     STEP_MARK(0);
@@ -524,15 +532,15 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     // hydrostatic integration -- are then short loops over LDS by ONE wave each (k = 0 and k = 1 run them side by side),
     // and everything else (tdt, divdt updates, phi write-out) is per (coefficient, level) again.  As one thread per
     // coefficient reading global memory level by level this phase was 40 us at T63 L16.
-    double *sdv = sm + (size_t)kx * 384, *st1 = sm + (size_t)kx * 512, *ssig = sm + (size_t)kx * 640;   // ssig: kx + 1 rows
-    double *smisc = ssig + (size_t)(kx + 1) * 128;                                                       // rows: dmean, psdt
+    double *sdv = sm + 3 * PL, *st1 = sm + 4 * PL, *ssig = sm + 5 * PL;                                  // ssig: kx + 1 rows
+    double *smisc = ssig + (size_t)(kx + 1) * 2 * BX;                                                     // rows: dmean, psdt
     put(sdv, k, ld(a.div, i));
     put(st1, k, ld(a.t, i));
     // implicit-solve operands, fetched now and consumed four barriers later (lds_sync leaves them in flight): this thread's row
     // of xj(:,:,l) into registers, its share of the xd / xc matrices (row-major copies, the same for every lane of a wave)
     // on the way to LDS.  Fetched where they are used, the three mat-vecs were half of this kernel's time.
     const int kxp = p.kxp;
-    double *sxd = smisc + 256, *sxc = sxd + kx * kxp;
+    double *sxd = smisc + 4 * BX, *sxc = sxd + kx * kxp;
     double2 xjr[4];                                             // (levels 8..15 of the row: fetched at the start of the solve)
     {
         const double2 *r2 = reinterpret_cast<const double2 *>(p.xjt + ((size_t)max(l - 1, 0) * kx + k) * kxp);
@@ -540,7 +548,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     }
     double cpd[2] = {0.0, 0.0}, cpc[2] = {0.0, 0.0};
     UNROLL for (int j = 0; j < 2; ++j) {
-        const int q = k * 64 + tx + j * 64 * kx;
+        const int q = k * BX + tx + j * BX * kx;
         if (q < kx * kxp) { cpd[j] = p.xdt[q]; cpc[j] = p.xct[q]; }
     }
     STEP_MARK(1);
@@ -591,7 +599,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         divdt = divdt - p.el2[ec] * (-x);
     }
     UNROLL for (int j = 0; j < 2; ++j) {
-        const int q = k * 64 + tx + j * 64 * kx;
+        const int q = k * BX + tx + j * BX * kx;
         if (q < kx * kxp) { sxd[q] = cpd[j]; sxc[q] = cpc[j]; }
     }
     lds_sync();                                            // (sy is reused by the implicit solve below)
@@ -602,7 +610,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     // ---- implicit_terms
     const double ez = p.elz[ec];
     {   // psdt lives with thread k == 0: broadcast through LDS scratch slot 0 of sy's fourth plane
-        double *sps = smisc + 128;
+        double *sps = smisc + 2 * BX;
         if (k == 0) { sps[2 * tx] = psdt.re; sps[2 * tx + 1] = psdt.im; }
         lds_sync();
         const cpx ps0 = {sps[2 * tx], sps[2 * tx + 1]};
@@ -693,18 +701,24 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
 __global__ __launch_bounds__(512, 2) void spectral_step_kernel(DevPlan p, SpecStep a) { spectral_step_body<4>(p, a); }
 __global__ __launch_bounds__(1024, 4) void spectral_step_kernel16(DevPlan p, SpecStep a) { spectral_step_body<8>(p, a); }
 
-size_t spectral_step_lds(int kx)   // 5 planes + (kx+1) sigma rows + 2 rows + row-major xd, xc
+// Coefficients per block.  16 (x kx level rows): with 64 the T63 launch was 65 blocks of up to 1024 threads whose three
+// kx-term mat-vecs went through ONE CU's LDS each; 260 blocks of a quarter the size use the whole chip (captured step
+// T63 L16 96.9 -> 92.2 us, T30 L16 57.1 -> 51.6 us; kx = 8: 0.5-1 us).  Needs 2 * bx >= kxp for the xd / xc staging.
+int spectral_step_bx(const DevPlan &) { return 16; }
+
+size_t spectral_step_lds(int kx, int bx)   // 5 planes + (kx+1) sigma rows + 2 rows + row-major xd, xc
 {
-    return ((size_t)(6 * kx + 3) * 128 + 2 * kx * ((kx + 1) & ~1)) * sizeof(double);
+    return ((size_t)(6 * kx + 3) * 2 * bx + 2 * kx * ((kx + 1) & ~1)) * sizeof(double);
 }
 
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s)
 {
     const int sz = p.mx * p.nx;
     if (p.kx > 16) return hipErrorInvalidValue;
-    const size_t lds = spectral_step_lds(p.kx);
-    if (p.kx <= 8) hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
-    else hipLaunchKernelGGL(spectral_step_kernel16, dim3((sz + 63) / 64), dim3(64, p.kx), lds, s, p, a);
+    const int bx = spectral_step_bx(p);
+    const size_t lds = spectral_step_lds(p.kx, bx);
+    if (p.kx <= 8) hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + bx - 1) / bx), dim3(bx, p.kx), lds, s, p, a);
+    else hipLaunchKernelGGL(spectral_step_kernel16, dim3((sz + bx - 1) / bx), dim3(bx, p.kx), lds, s, p, a);
     return hipGetLastError();
 }
 
