@@ -84,11 +84,16 @@ __global__ void implicit_kernel(DevPlan p, double *__restrict__ divdt, double *_
 
 static size_t implicit_lds(int kx) { return (size_t)3 * kx * 64 * 16; }
 
-size_t spectral_step_lds(int kx, int bx = 16);
+constexpr size_t spectral_step_lds(int kx, int bx = 16)   // 5 planes + (kx+1) sigma rows + 2 rows + row-major xd, xc + 5 level tables + 4 planes and a row (time level 2)
+{
+    return ((size_t)(6 * kx + 3) * 2 * bx + 2 * kx * ((kx + 1) & ~1) + ((5 * kx + 1) & ~1) + (size_t)(4 * kx + 1) * 2 * bx) * sizeof(double);
+}
+constexpr size_t spectral_step_lds_max() { return spectral_step_lds(16); }
 size_t grid_tendencies_lds(int kx, int bx = 16);
 __global__ void grid_tendencies_kernel(DevPlan p, GridTend g);
+constexpr int STEP_BX = 16;          // coefficients per block of the one-launch spectral step
+template <int NJ, bool FULL>
 __global__ void spectral_step_kernel(DevPlan p, SpecStep a);
-__global__ void spectral_step_kernel16(DevPlan p, SpecStep a);
 
 hipError_t prepare_device_step_kernels(int kx)
 {
@@ -102,9 +107,7 @@ hipError_t prepare_device_step_kernels(int kx)
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)implicit_lds(kx));
         if (e != hipSuccess) return e;
     }
-    if (kx <= 16 && spectral_step_lds(kx) > 64 * 1024)
-        return hipFuncSetAttribute(kx <= 8 ? reinterpret_cast<const void *>(spectral_step_kernel) : reinterpret_cast<const void *>(spectral_step_kernel16),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)spectral_step_lds(kx));
+    static_assert(spectral_step_lds_max() <= 64 * 1024, "the one-launch spectral step fits the default dynamic LDS limit");
     return hipSuccess;
 }
 
@@ -475,12 +478,15 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // ------------------------------------------------------------------------------------------
 // NJ = 16-byte pieces of a mat-vec row held in registers: 4 for up to 8 levels (512 threads, 256 VGPRs), 8 for up to 16
 // (1024 threads, 128 VGPRs)
-template <int NJ>
+// FULL: the level count IS the bound (8 or 16, the reference's and config 5's): every `kk < kx` guard and index clamp of the
+// unrolled level loops folds away.  The level recurrences are executed by ONE wave while the block waits, so their
+// instruction count (not a latency) is what the block pays: 1300 instructions at 4 cycles each were 2.7 us at kx = 16.
+template <int NJ, bool FULL>
 __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecStep &a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];           // complex planes [kx][64]: divdt, tdt, phi / yf / d, div, t; + rows
-    const int kx = p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
-    const int BX = blockDim.x;                                             // coefficients per block (16, 32 or 64)
+    const int kx = FULL ? 2 * NJ : p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
+    constexpr int BX = STEP_BX;                                            // coefficients per block: LDS offsets are immediates
     const int e = blockIdx.x * BX + tx;
     const bool valid = e < sz;
     const int ec = valid ? e : sz - 1, m = ec % p.mx, n = ec / p.mx, l = m + n;
@@ -491,6 +497,14 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     auto get = [&](double *b, int kk) { return cpx{at(b, kk)[0], at(b, kk)[1]}; };
     auto put = [&](double *b, int kk, cpx z) { at(b, kk)[0] = z.re; at(b, kk)[1] = z.im; };
     STEP_MARK(0);
+    // Everything the kernel reads from global memory at a fixed place is requested HERE, in one batch with the tendencies:
+    // time level 2 of the prognostics (consumed by the leapfrog at the very end, parked in LDS meanwhile), the surface
+    // geopotential and the surface-pressure tendency (consumed by one level row each, but a load under a lane-dependent
+    // condition is a branch and a full wait).  Requested where they are used, each was one more trip to memory on the block's
+    // critical path.
+    const long lvl2 = (long)kx * sz;
+    const cpx vor2 = ld(a.vor, lvl2 + i), div2 = ld(a.div, lvl2 + i), t2 = ld(a.t, lvl2 + i), tr2 = ld(a.tr, lvl2 + i);
+    const cpx ps2 = ld(a.ps, sz + ec), phs = ld(a.phis, ec), psdt_in = ld(a.pspec, (long)3 * kx * sz + ec);
     // ---- tendency combination on the direct batch's outputs
     cpx vordt, pd0, pd1, pd2;
     if (a.raw_u) {
@@ -532,6 +546,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     // hydrostatic integration -- are then short loops over LDS by ONE wave each (k = 0 and k = 1 run them side by side),
     // and everything else (tdt, divdt updates, phi write-out) is per (coefficient, level) again.  As one thread per
     // coefficient reading global memory level by level this phase was 40 us at T63 L16.
+    const cpx ps1 = ld(a.ps, ec);
     double *sdv = sm + 3 * PL, *st1 = sm + 4 * PL, *ssig = sm + 5 * PL;                                  // ssig: kx + 1 rows
     double *smisc = ssig + (size_t)(kx + 1) * 2 * BX;                                                     // rows: dmean, psdt
     put(sdv, k, ld(a.div, i));
@@ -539,7 +554,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     // implicit-solve operands, fetched now and consumed four barriers later (lds_sync leaves them in flight): this thread's row
     // of xj(:,:,l) into registers, its share of the xd / xc matrices (row-major copies, the same for every lane of a wave)
     // on the way to LDS.  Fetched where they are used, the three mat-vecs were half of this kernel's time.
-    const int kxp = p.kxp;
+    const int kxp = FULL ? 2 * NJ : p.kxp;
     double *sxd = smisc + 4 * BX, *sxc = sxd + kx * kxp;
     double2 xjr[4];                                             // (levels 8..15 of the row: fetched at the start of the solve)
     {
@@ -551,39 +566,70 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         const int q = k * BX + tx + j * BX * kx;
         if (q < kx * kxp) { cpd[j] = p.xdt[q]; cpc[j] = p.xct[q]; }
     }
+    // per-level tables of the level recurrences below, into LDS: rows dhs, xgeop1, xgeop2, corf, dhsx.  (Read from global
+    // memory inside the recurrences, every iteration waited for its own scalar loads: 7.7 us of this kernel at T63 L16.)
+    constexpr int KM = 2 * NJ;                                  // level count bound of this instantiation (8 or 16)
+    double *stb = sxc + kx * kxp;
+    {
+        const int q = k * BX + tx;
+        if (q < kx) {
+            stb[q] = p.dhs[q]; stb[kx + q] = p.xgeop1[q]; stb[2 * kx + q] = p.xgeop2[q]; stb[3 * kx + q] = p.corf[q];
+            stb[4 * kx + q] = p.dhsx[q];
+        }
+    }
+    double *sl2 = stb + ((5 * kx + 1) & ~1);                    // planes vor2, div2, t2, tr2 + a row for ps2
     STEP_MARK(1);
     lds_sync();
     STEP_MARK(2);
+    put(sl2, k, vor2); put(sl2 + PL, k, div2); put(sl2 + 2 * PL, k, t2); put(sl2 + 3 * PL, k, tr2);
+    if (k == 0) put(sl2 + 4 * PL, 0, ps2);
     cpx psdt = {0.0, 0.0};
+    // The recurrences run over registers: every level's operands are fetched from LDS first (one batch of reads at fixed
+    // offsets, indices clamped to kx - 1), the dependent chain is then arithmetic only.
     if (k == 0) {                                               // vertical mean, surface-pressure tendency, sigma-dot (:256-275)
-        psdt = ld(a.pspec, (long)3 * kx * sz + ec);
+        psdt = psdt_in;
+        cpx dv[KM];
+        double dh[KM];
+        UNROLL for (int kk = 0; kk < KM; ++kk) { const int kc = min(kk, kx - 1); dv[kk] = get(sdv, kc); dh[kk] = stb[kc]; }
         if (ec == 0) psdt = {0.0, 0.0};                                    // tendencies.f90:126
         cpx dmean = {0.0, 0.0};
-        for (int kk = 0; kk < kx; ++kk) dmean = dmean + p.dhs[kk] * get(sdv, kk);
+        UNROLL for (int kk = 0; kk < KM; ++kk) if (kk < kx) dmean = dmean + dh[kk] * dv[kk];
         psdt = psdt - dmean;
         if (ec == 0) psdt = {0.0, 0.0};
         put(smisc, 0, dmean);
         cpx sig = {0.0, 0.0};
         put(ssig, 0, sig);
-        for (int kk = 0; kk < kx; ++kk) {
+        UNROLL for (int kk = 0; kk < KM; ++kk) if (kk < kx) {
             cpx sig1 = {0.0, 0.0};
-            if (kk < kx - 1) sig1 = sig - p.dhs[kk] * (get(sdv, kk) - dmean);
+            if (kk < kx - 1) sig1 = sig - dh[kk] * (dv[kk] - dmean);
             put(ssig, kk + 1, sig1);
             sig = sig1;
         }
     }
-    if (k == (kx > 1 ? 1 : 0)) {                                // get_geopotential (geopotential.f90:33-57) into the sy plane
+    // (on another wave than the loops above where the block has one: BX = 16 puts four level rows into a wave)
+    if (k == min(kx - 1, max(1, 64 / BX))) {                     // get_geopotential (geopotential.f90:33-57) into the sy plane
         const bool zonal = m == 0;
+        cpx tk[KM];
+        UNROLL for (int kk = 0; kk < KM; ++kk) tk[kk] = get(st1, min(kk, kx - 1));
         cpx tk1 = get(st1, kx - 1);
-        cpx ph = ld(a.phis, ec) + p.xgeop1[kx - 1] * tk1;
+        cpx ph = phs + stb[kx + kx - 1] * tk1;
         put(sy, kx - 1, ph);
-        for (int kk = kx - 2; kk >= 0; --kk) {
-            const cpx tk = get(st1, kk);
-            ph = (ph + p.xgeop2[kk + 1] * tk1) + p.xgeop1[kk] * tk;
-            cpx out = ph;
-            if (zonal && kk >= 1) out = ph + p.corf[kk] * (tk1 - get(st1, kk - 1));
-            put(sy, kk, out);
-            tk1 = tk;
+        UNROLL for (int hb = KM - 8; hb >= 0; hb -= 8) {         // the table rows eight levels at a time (registers)
+            double g1[8], g2n[8], cf[8];                         // xgeop1[kk], xgeop2[kk + 1], corf[kk] of kk = hb .. hb + 7
+            UNROLL for (int j = 0; j < 8; ++j) {
+                const int kc = min(hb + j, kx - 1);
+                g1[j] = stb[kx + kc]; g2n[j] = stb[2 * kx + min(hb + j + 1, kx - 1)]; cf[j] = stb[3 * kx + kc];
+            }
+            UNROLL for (int kk = hb + 7; kk >= hb; --kk) if (kk <= KM - 2 && kk <= kx - 2) {
+                ph = (ph + g2n[kk - hb] * tk1) + g1[kk - hb] * tk[kk];
+                cpx out = ph;
+                if (kk >= 1) {
+                    const cpx oz = ph + cf[kk - hb] * (tk1 - tk[kk - 1]);
+                    if (zonal) out = oz;
+                }
+                put(sy, kk, out);
+                tk1 = tk[kk];
+            }
         }
     }
     lds_sync();
@@ -595,7 +641,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         tdt = ((tdt - p.dhsr[k] * (dumk1 + dumk)) + p.tref3[k] * (sig1 + sig)) - p.tref2[k] * dmean;
         const cpx ph = get(sy, k);
         if (valid) st(a.phi, i, ph);
-        const cpx x = (valid ? ph : cpx{0.0, 0.0}) + p.rgtref[k] * ld(a.ps, ec);
+        const cpx x = (valid ? ph : cpx{0.0, 0.0}) + p.rgtref[k] * ps1;
         divdt = divdt - p.el2[ec] * (-x);
     }
     UNROLL for (int j = 0; j < 2; ++j) {
@@ -615,8 +661,11 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         lds_sync();
         const cpx ps0 = {sps[2 * tx], sps[2 * tx + 1]};
         // mat-vec rows from the row-major copies; the sums keep the reference's order k1 = 0..kx-1
-        auto matvec = [&](const double *row, double *src, cpx acc) {                 // row in LDS (broadcast reads)
-            for (int k1 = 0; k1 < kx; ++k1) acc = acc + row[k1] * get(src, k1);
+        auto matvec = [&](const double *row, double *src, cpx acc) {                 // row in LDS; operands first, then the chain
+            cpx v[KM];
+            double r[KM];
+            UNROLL for (int k1 = 0; k1 < KM; ++k1) { const int kc = min(k1, kx - 1); v[k1] = get(src, kc); r[k1] = row[kc]; }
+            UNROLL for (int k1 = 0; k1 < KM; ++k1) if (k1 < kx) acc = acc + r[k1] * v[k1];
             return acc;
         };
         double2 xjl[4];
@@ -629,24 +678,29 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         put(sy, k, get(sdiv, k) + ez * ye);                                // yf
         lds_sync();
         cpx d = {0.0, 0.0};
-        if (l != 0) {
+        {
+            cpx yv[KM];
+            UNROLL for (int k1 = 0; k1 < KM; ++k1) yv[k1] = get(sy, min(k1, kx - 1));
             UNROLL for (int j = 0; j < 4; ++j) {
-                if (2 * j < kx) d = d + xjr[j].x * get(sy, 2 * j);
-                if (2 * j + 1 < kx) d = d + xjr[j].y * get(sy, 2 * j + 1);
+                if (2 * j < kx) d = d + xjr[j].x * yv[2 * j];
+                if (2 * j + 1 < kx) d = d + xjr[j].y * yv[2 * j + 1];
             }
             if (NJ > 4) {
                 UNROLL for (int j = 4; j < 8; ++j) {
-                    if (2 * j < kx) d = d + xjl[j - 4].x * get(sy, 2 * j);
-                    if (2 * j + 1 < kx) d = d + xjl[j - 4].y * get(sy, 2 * j + 1);
+                    if (2 * j < kx) d = d + xjl[j - 4].x * yv[2 * j];
+                    if (2 * j + 1 < kx) d = d + xjl[j - 4].y * yv[2 * j + 1];
                 }
             }
+            if (l == 0) d = {0.0, 0.0};
         }
         lds_sync();
         put(sy, k, d);                                                     // divdt after the solve
         lds_sync();
         if (k == 0) {
-            cpx ps = ps0;
-            for (int kk = 0; kk < kx; ++kk) ps = ps - p.dhsx[kk] * get(sy, kk);
+            cpx ps = ps0, dk[KM];
+            double hx[KM];
+            UNROLL for (int kk = 0; kk < KM; ++kk) { const int kc = min(kk, kx - 1); dk[kk] = get(sy, kc); hx[kk] = stb[4 * kx + kc]; }
+            UNROLL for (int kk = 0; kk < KM; ++kk) if (kk < kx) ps = ps - hx[kk] * dk[kk];
             psdt = ps;
         }
         tdt = matvec(sxc + k * kxp, sy, get(stdt, k));
@@ -655,13 +709,14 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     STEP_MARK(5);
     if (!valid) return;
     // ---- diffusion block of step() (time level 1 of the prognostics)
+    cpx vo, dv, t1v, tr1;
     {
         const double dmp = p.dmp_t[0][ec], dmpd = p.dmp_t[1][ec], dmps = p.dmp_t[2][ec];
         const double dmp1 = p.dmp_t[3][ec], dmp1d = p.dmp_t[4][ec], dmp1s = p.dmp_t[5][ec];
-        const cpx vo = ld(a.vor, i), dv = ld(a.div, i);
+        vo = ld(a.vor, i); dv = ld(a.div, i); t1v = ld(a.t, i); tr1 = ld(a.tr, i);
         vordt = hd(vo, vordt, dmp, dmp1);
         divdt = hd(dv, divdt, dmpd, dmp1d);
-        const cpx ctmp = ld(a.t, i) + p.tcorv[k] * ld(a.tcorh, ec);
+        const cpx ctmp = t1v + p.tcorv[k] * ld(a.tcorh, ec);
         tdt = hd(ctmp, tdt, dmp, dmp1);
         if (m == 0 && k == 0) {
             vordt = vordt - a.sdrag * vo;
@@ -670,18 +725,16 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         vordt = hd(vo, vordt, dmps, dmp1s);
         divdt = hd(dv, divdt, dmps, dmp1s);
         tdt = hd(ctmp, tdt, dmps, dmp1s);
-        const cpx cq = ld(a.tr, i) + p.qcorv[k] * ld(a.qcorh, ec);
+        const cpx cq = tr1 + p.qcorv[k] * ld(a.qcorh, ec);
         trdt = hd(cq, trdt, dmpd, dmp1d);
     }
     STEP_MARK(6);
     // ---- step_field_3d for vor, div, t, tr and step_field_2d for ps; tendencies written back truncated, as the
     // separate kernels leave them
     const double trf = p.trfilt[ec];
-    const long lvl2 = (long)kx * sz;
-    auto stepf = [&](double *f, long idx, long off2, cpx fd, double *fdt_out, long fdt_idx) {
+    auto stepf = [&](double *f, long idx, long off2, cpx o1, cpx o2, cpx fd, double *fdt_out, long fdt_idx) {
         if (a.do_trunct) fd = trf * fd;
         st(fdt_out, fdt_idx, fd);
-        const cpx o1 = ld(f, idx), o2 = ld(f, off2 + idx);
         const cpx fnew = o1 + a.dt * fd;
         const cpx oj = a.j1 == 1 ? o1 : o2;
         const cpx n1 = oj + (a.wil * a.eps) * ((o1 - 2.0 * oj) + fnew);
@@ -690,26 +743,23 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         st(f, idx, n1);
         st(f, off2 + idx, n2);
     };
-    stepf(a.vor, i, lvl2, vordt, a.pvor, i);
-    stepf(a.div, i, lvl2, divdt, a.pdiv, i);
-    stepf(a.t, i, lvl2, tdt, a.pdiv, (long)kx * sz + i);
-    stepf(a.tr, i, lvl2, trdt, a.pdiv, (long)2 * kx * sz + i);
-    if (k == 0) stepf(a.ps, ec, sz, psdt, a.pspec, (long)3 * kx * sz + ec);
+    // (each thread reads back what it parked itself: no barrier needed)
+    stepf(a.vor, i, lvl2, vo, get(sl2, k), vordt, a.pvor, i);
+    stepf(a.div, i, lvl2, dv, get(sl2 + PL, k), divdt, a.pdiv, i);
+    stepf(a.t, i, lvl2, t1v, get(sl2 + 2 * PL, k), tdt, a.pdiv, (long)kx * sz + i);
+    stepf(a.tr, i, lvl2, tr1, get(sl2 + 3 * PL, k), trdt, a.pdiv, (long)2 * kx * sz + i);
+    if (k == 0) stepf(a.ps, ec, sz, ps1, get(sl2 + 4 * PL, 0), psdt, a.pspec, (long)3 * kx * sz + ec);
     STEP_MARK(7);
 }
 
-__global__ __launch_bounds__(512, 2) void spectral_step_kernel(DevPlan p, SpecStep a) { spectral_step_body<4>(p, a); }
-__global__ __launch_bounds__(1024, 4) void spectral_step_kernel16(DevPlan p, SpecStep a) { spectral_step_body<8>(p, a); }
+// blocks of 16 x kx threads: NJ = 4 up to 8 levels, NJ = 8 up to 16 (two waves per SIMD: 260 blocks at T63 must not need two rounds)
+template <int NJ, bool FULL>
+__global__ __launch_bounds__(STEP_BX * 2 * NJ, NJ > 4 ? 2 : 1) void spectral_step_kernel(DevPlan p, SpecStep a) { spectral_step_body<NJ, FULL>(p, a); }
 
 // Coefficients per block.  16 (x kx level rows): with 64 the T63 launch was 65 blocks of up to 1024 threads whose three
 // kx-term mat-vecs went through ONE CU's LDS each; 260 blocks of a quarter the size use the whole chip (captured step
 // T63 L16 96.9 -> 92.2 us, T30 L16 57.1 -> 51.6 us; kx = 8: 0.5-1 us).  Needs 2 * bx >= kxp for the xd / xc staging.
-int spectral_step_bx(const DevPlan &) { return 16; }
-
-size_t spectral_step_lds(int kx, int bx)   // 5 planes + (kx+1) sigma rows + 2 rows + row-major xd, xc
-{
-    return ((size_t)(6 * kx + 3) * 2 * bx + 2 * kx * ((kx + 1) & ~1)) * sizeof(double);
-}
+int spectral_step_bx(const DevPlan &) { return STEP_BX; }
 
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s)
 {
@@ -717,8 +767,11 @@ hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t
     if (p.kx > 16) return hipErrorInvalidValue;
     const int bx = spectral_step_bx(p);
     const size_t lds = spectral_step_lds(p.kx, bx);
-    if (p.kx <= 8) hipLaunchKernelGGL(spectral_step_kernel, dim3((sz + bx - 1) / bx), dim3(bx, p.kx), lds, s, p, a);
-    else hipLaunchKernelGGL(spectral_step_kernel16, dim3((sz + bx - 1) / bx), dim3(bx, p.kx), lds, s, p, a);
+    const dim3 grd((sz + bx - 1) / bx), blk(bx, p.kx);
+    if (p.kx == 8) hipLaunchKernelGGL((spectral_step_kernel<4, true>), grd, blk, lds, s, p, a);
+    else if (p.kx < 8) hipLaunchKernelGGL((spectral_step_kernel<4, false>), grd, blk, lds, s, p, a);
+    else if (p.kx == 16) hipLaunchKernelGGL((spectral_step_kernel<8, true>), grd, blk, lds, s, p, a);
+    else hipLaunchKernelGGL((spectral_step_kernel<8, false>), grd, blk, lds, s, p, a);
     return hipGetLastError();
 }
 
