@@ -89,19 +89,15 @@ constexpr size_t spectral_step_lds(int kx, int bx = 16)   // 5 planes + (kx+1) s
     return ((size_t)(6 * kx + 3) * 2 * bx + 2 * kx * ((kx + 1) & ~1) + ((5 * kx + 1) & ~1) + (size_t)(4 * kx + 1) * 2 * bx) * sizeof(double);
 }
 constexpr size_t spectral_step_lds_max() { return spectral_step_lds(16); }
-size_t grid_tendencies_lds(int kx, int bx = 16);
-__global__ void grid_tendencies_kernel(DevPlan p, GridTend g);
+constexpr int GT_BX = 16;            // grid points per block of the grid-tendencies kernel
+constexpr size_t grid_tendencies_lds(int kx, int bx = GT_BX) { return ((size_t)(6 * kx + 2 * (kx + 1) + 3) * bx + kx) * sizeof(double); }
 constexpr int STEP_BX = 16;          // coefficients per block of the one-launch spectral step
 template <int NJ, bool FULL>
 __global__ void spectral_step_kernel(DevPlan p, SpecStep a);
 
 hipError_t prepare_device_step_kernels(int kx)
 {
-    if (kx <= 16 && grid_tendencies_lds(kx) > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_tendencies_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)grid_tendencies_lds(kx));
-        if (e != hipSuccess) return e;
-    }
+    static_assert(grid_tendencies_lds(16) <= 64 * 1024, "the grid-tendencies kernel fits the default dynamic LDS limit");
     if (implicit_lds(kx) > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(implicit_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)implicit_lds(kx));
@@ -353,11 +349,14 @@ __global__ void grid_tendencies_serial_kernel(DevPlan p, GridTend g)
 // (one coalesced memory round trip for the block instead of one per level of a serial per-point loop: 24 -> see DESIGN at
 // T63 L16); the vertical means and the sigma-dot prefix sums are short loops over LDS by wave 0, everything else is per
 // (point, level) with the neighbouring levels read from LDS.  Expressions as in the reference's loops.
-__global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
+// KM: level count bound of the instantiation (8 or 16); FULL: kx == KM, the level loops' guards fold (they are ONE wave's
+// instruction stream while the block waits, like the recurrences of the spectral step).
+template <int KM, bool FULL>
+__global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, GridTend g)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int gsz = p.ix * p.il, kx = p.kx, tx = threadIdx.x, k = threadIdx.y;
-    const int BX = blockDim.x;                                             // grid points per block
+    const int gsz = p.ix * p.il, kx = FULL ? KM : p.kx, tx = threadIdx.x, k = threadIdx.y;
+    constexpr int BX = GT_BX;                                              // grid points per block
     const int i0 = blockIdx.x * BX + tx;
     const bool valid = i0 < gsz;
     const int i = valid ? i0 : gsz - 1, j = i / p.ix;
@@ -376,11 +375,15 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
     lds_sync();
     if (k == 0) {                                                                          // vertical means (:109-117)
         double umean = 0.0, vmean = 0.0, dmean = 0.0;
-        for (int kk = 0; kk < kx; ++kk) {
-            const double dh = stab[kk];
-            umean = umean + S(su, kk) * dh;
-            vmean = vmean + S(sv, kk) * dh;
-            dmean = dmean + S(sd, kk) * dh;
+        double cu[KM], cv[KM], cd[KM], dh[KM];                                             // operands first, then the chains
+        UNROLL for (int kk = 0; kk < KM; ++kk) {
+            const int kc = min(kk, kx - 1);
+            cu[kk] = S(su, kc); cv[kk] = S(sv, kc); cd[kk] = S(sd, kc); dh[kk] = stab[kc];
+        }
+        UNROLL for (int kk = 0; kk < KM; ++kk) if (kk < kx) {
+            umean = umean + cu[kk] * dh[kk];
+            vmean = vmean + cv[kk] * dh[kk];
+            dmean = dmean + cd[kk] * dh[kk];
         }
         smean[tx] = umean; smean[BX + tx] = vmean; smean[2 * BX + tx] = dmean;
     }
@@ -392,10 +395,11 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
     if (k == 0) {                                                                          // sigdt, sigm at the half levels (:139-142)
         double sig = 0.0, sigm = 0.0;
         S(ssig, 0) = 0.0; S(ssigm, 0) = 0.0;
-        for (int kk = 0; kk < kx; ++kk) {
-            const double dh = stab[kk], pk = S(sp, kk);
-            sig = sig - dh * (pk + S(sd, kk) - dmean);
-            sigm = sigm - dh * pk;
+        double cp[KM], cd[KM], dh[KM];
+        UNROLL for (int kk = 0; kk < KM; ++kk) { const int kc = min(kk, kx - 1); cp[kk] = S(sp, kc); cd[kk] = S(sd, kc); dh[kk] = stab[kc]; }
+        UNROLL for (int kk = 0; kk < KM; ++kk) if (kk < kx) {
+            sig = sig - dh[kk] * (cp[kk] + cd[kk] - dmean);
+            sigm = sigm - dh[kk] * cp[kk];
             S(ssig, kk + 1) = sig; S(ssigm, kk + 1) = sigm;
         }
     }
@@ -431,7 +435,6 @@ __global__ void grid_tendencies_kernel(DevPlan p, GridTend g)
 #undef S
 }
 
-size_t grid_tendencies_lds(int kx, int bx) { return ((size_t)(6 * kx + 2 * (kx + 1) + 3) * bx + kx) * sizeof(double); }
 
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s)
 {
@@ -440,8 +443,13 @@ hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream
     else {
         // 16 points x kx levels per block: at model sizes the kernel is a latency chain per block, and 4x as many (smaller)
         // blocks spread its LDS traffic and loads over 4x as many CUs (T30: 72 -> 288 blocks; T63 L16 step 92.3 -> 89.2 us)
-        const int bx = 16;
-        hipLaunchKernelGGL(grid_tendencies_kernel, dim3((gsz + bx - 1) / bx), dim3(bx, p.kx), grid_tendencies_lds(p.kx, bx), s, p, g);
+        constexpr int bx = GT_BX;
+        const dim3 grd((gsz + bx - 1) / bx), blk(bx, p.kx);
+        const size_t lds = grid_tendencies_lds(p.kx, bx);
+        if (p.kx == 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, true>), grd, blk, lds, s, p, g);
+        else if (p.kx < 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, false>), grd, blk, lds, s, p, g);
+        else if (p.kx == 16) hipLaunchKernelGGL((grid_tendencies_kernel<16, true>), grd, blk, lds, s, p, g);
+        else hipLaunchKernelGGL((grid_tendencies_kernel<16, false>), grd, blk, lds, s, p, g);
     }
     return hipGetLastError();
 }
