@@ -12,6 +12,16 @@ module spdy_c
         type(c_ptr) :: d_spec
     end type
 
+    !> spdy_hdiff_op, spdy_step_op (include/spdy.h): one array of spdy_hdiff_multi_dev / spdy_step_fields_dev
+    type, bind(C) :: spdy_hdiff_op
+        integer(c_int) :: nlev
+        type(c_ptr) :: field, fdt_in, d_dmp, d_dmp1, fdt_out
+    end type
+    type, bind(C) :: spdy_step_op
+        integer(c_int) :: nlev
+        type(c_ptr) :: field, fdt
+    end type
+
     interface
         function spdy_plan_create(trunc, ix, iy, kx, max_batch, device, plan) bind(C, name="spdy_plan_create") result(rc)
             import :: c_int, c_ptr
@@ -288,6 +298,243 @@ module spdy_c
             type(c_ptr), value :: plan, d_ug, d_vg, d_grid, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi
             integer(c_int), value :: kcos, j1
             real(c_double), value :: sdrag, dt, eps, wil
+            integer(c_int) :: rc
+        end function
+        ! ---- the rest of include/spdy.h, one interface per entry point (device pointers are type(c_ptr) values) ----
+        function spdy_plan_set_stream(plan, hip_stream) bind(C, name="spdy_plan_set_stream") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, hip_stream
+            integer(c_int) :: rc
+        end function
+        function spdy_plan_set_profiling(plan, on) bind(C, name="spdy_plan_set_profiling") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: on
+            integer(c_int) :: rc
+        end function
+        function spdy_plan_set_fused(plan, mode) bind(C, name="spdy_plan_set_fused") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: mode
+            integer(c_int) :: rc
+        end function
+        function spdy_plan_get_profile(plan, ms, launches) bind(C, name="spdy_plan_get_profile") result(rc)
+            import :: c_double, c_int, c_ptr
+            type(c_ptr), value :: plan
+            real(c_double), intent(out) :: ms(*)
+            integer(c_int), intent(out) :: launches(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_plan_dims(plan, dims) bind(C, name="spdy_plan_dims") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), intent(out) :: dims(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_spec_to_grid_dev(plan, nb, d_spec, d_kcos, kcos_all, d_grid) &
+                & bind(C, name="spdy_spec_to_grid_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_spec, d_kcos, d_grid
+            integer(c_int), value :: nb, kcos_all
+            integer(c_int) :: rc
+        end function
+        function spdy_grid_to_spec_dev(plan, nb, d_grid, d_spec) bind(C, name="spdy_grid_to_spec_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_grid, d_spec
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_legendre_inv(plan, nb, spec, four) bind(C, name="spdy_legendre_inv") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            type(*), intent(in) :: spec(*)
+            type(*) :: four(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_legendre_dir(plan, nb, four, spec) bind(C, name="spdy_legendre_dir") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            type(*), intent(in) :: four(*)
+            type(*) :: spec(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_fourier_inv(plan, nb, four, kcos, grid) bind(C, name="spdy_fourier_inv") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb, kcos
+            type(*), intent(in) :: four(*)
+            type(*) :: grid(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_fourier_dir(plan, nb, grid, four) bind(C, name="spdy_fourier_dir") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nb
+            type(*), intent(in) :: grid(*)
+            type(*) :: four(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_laplacian_dev(plan, nb, in, out) bind(C, name="spdy_laplacian_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, in, out
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_inverse_laplacian_dev(plan, nb, in, out) bind(C, name="spdy_inverse_laplacian_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, in, out
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_trunct_dev(plan, nb, inout) bind(C, name="spdy_trunct_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, inout
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_grad_dev(plan, nb, psi, psdx, psdy) bind(C, name="spdy_grad_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, psi, psdx, psdy
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_vds_dev(plan, nb, ucosm, vcosm, vorm, divm) bind(C, name="spdy_vds_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, ucosm, vcosm, vorm, divm
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_uvspec_dev(plan, nb, vorm, divm, ucosm, vcosm) bind(C, name="spdy_uvspec_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, vorm, divm, ucosm, vcosm
+            integer(c_int), value :: nb
+            integer(c_int) :: rc
+        end function
+        function spdy_vdspec_dev(plan, nb, ug, vg, vorm, divm, kcos) bind(C, name="spdy_vdspec_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, ug, vg, vorm, divm
+            integer(c_int), value :: nb, kcos
+            integer(c_int) :: rc
+        end function
+        function spdy_hdiff_dev(plan, nlev, field, fdt_in, d_dmp, d_dmp1, fdt_out) bind(C, name="spdy_hdiff_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, field, fdt_in, d_dmp, d_dmp1, fdt_out
+            integer(c_int), value :: nlev
+            integer(c_int) :: rc
+        end function
+        function spdy_hdiff_multi_dev(plan, nops, ops) bind(C, name="spdy_hdiff_multi_dev") result(rc)
+            import :: c_int, c_ptr, spdy_hdiff_op
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nops
+            type(spdy_hdiff_op), intent(in) :: ops(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_implicit_terms_dev(plan, divdt, tdt, psdt) bind(C, name="spdy_implicit_terms_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, divdt, tdt, psdt
+            integer(c_int) :: rc
+        end function
+        function spdy_device_table(plan, name, d_ptr) bind(C, name="spdy_device_table") result(rc)
+            import :: c_char, c_int, c_ptr
+            type(c_ptr), value :: plan
+            character(kind=c_char), intent(in) :: name(*)
+            type(c_ptr), intent(out) :: d_ptr
+            integer(c_int) :: rc
+        end function
+        function spdy_geopotential_dev(plan, t, phis, phi) bind(C, name="spdy_geopotential_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, t, phis, phi
+            integer(c_int) :: rc
+        end function
+        function spdy_spectral_tendencies_dev(plan, div, t, ps, phis, divdt, tdt, psdt, phi) &
+                & bind(C, name="spdy_spectral_tendencies_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, div, t, ps, phis, divdt, tdt, psdt, phi
+            integer(c_int) :: rc
+        end function
+        function spdy_hdiff_step_dev(plan, vor, div, t, tr, d_tcorh, d_qcorh, sdrag, vordt, divdt, tdt, trdt) &
+                & bind(C, name="spdy_hdiff_step_dev") result(rc)
+            import :: c_double, c_int, c_ptr
+            type(c_ptr), value :: plan, vor, div, t, tr, d_tcorh, d_qcorh, vordt, divdt, tdt, trdt
+            real(c_double), value :: sdrag
+            integer(c_int) :: rc
+        end function
+        function spdy_step_fields_dev(plan, nops, ops, j1, dt, eps, wil) bind(C, name="spdy_step_fields_dev") result(rc)
+            import :: c_double, c_int, c_ptr, spdy_step_op
+            type(c_ptr), value :: plan
+            integer(c_int), value :: nops, j1
+            type(spdy_step_op), intent(in) :: ops(*)
+            real(c_double), value :: dt, eps, wil
+            integer(c_int) :: rc
+        end function
+        function spdy_tendency_combine_dev(plan, pdiv, pspec) bind(C, name="spdy_tendency_combine_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, pdiv, pspec
+            integer(c_int) :: rc
+        end function
+        function spdy_spectral_step_dev(plan, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, sdrag, j1, &
+                & dt, eps, wil, phi) &
+                & bind(C, name="spdy_spectral_step_dev") result(rc)
+            import :: c_double, c_int, c_ptr
+            type(c_ptr), value :: plan, pvor, pdiv, pspec, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi
+            real(c_double), value :: sdrag, dt, eps, wil
+            integer(c_int), value :: j1
+            integer(c_int) :: rc
+        end function
+        function spdy_allgather_levels_dev(comm, nlev, narr, d_full) bind(C, name="spdy_allgather_levels_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm
+            integer(c_int), value :: nlev, narr
+            type(c_ptr), intent(in) :: d_full(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_uvspec_to_grid_dev(plan, nb, d_vor, d_div, d_ug, d_vg, kcos) &
+                & bind(C, name="spdy_uvspec_to_grid_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_vor, d_div, d_ug, d_vg
+            integer(c_int), value :: nb, kcos
+            integer(c_int) :: rc
+        end function
+        function spdy_grad_to_grid_dev(plan, nb, d_psi, d_gx, d_gy, kcos) bind(C, name="spdy_grad_to_grid_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_psi, d_gx, d_gy
+            integer(c_int), value :: nb, kcos
+            integer(c_int) :: rc
+        end function
+        function spdy_inverse_batch_dev(plan, npairs, d_vor, d_div, d_ug, d_vg, kcos_pairs, nplain, d_spec, d_kcos, &
+                & kcos_all, d_grid) &
+                & bind(C, name="spdy_inverse_batch_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_vor, d_div, d_ug, d_vg, d_spec, d_kcos, d_grid
+            integer(c_int), value :: npairs, kcos_pairs, nplain, kcos_all
+            integer(c_int) :: rc
+        end function
+        function spdy_direct_batch_dev(plan, npairs, d_ug, d_vg, d_vorm, d_divm, kcos, nplain, d_grid, d_spec) &
+                & bind(C, name="spdy_direct_batch_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_ug, d_vg, d_vorm, d_divm, d_grid, d_spec
+            integer(c_int), value :: npairs, kcos, nplain
+            integer(c_int) :: rc
+        end function
+        function spdy_inverse_batch_grad_dev(plan, npairs, d_vor, d_div, d_ug, d_vg, kcos_pairs, nplain, d_spec, d_kcos, &
+                & kcos_all, d_grid, ngrad, d_psi, d_gx, d_gy, kcos_grad) &
+                & bind(C, name="spdy_inverse_batch_grad_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, d_vor, d_div, d_ug, d_vg, d_spec, d_kcos, d_grid, d_psi, d_gx, d_gy
+            integer(c_int), value :: npairs, kcos_pairs, nplain, kcos_all, ngrad, kcos_grad
+            integer(c_int) :: rc
+        end function
+        function spdy_output_workspace(plan) bind(C, name="spdy_output_workspace") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int) :: rc
+        end function
+        function spdy_output_batch_dev(plan, vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out) &
+                & bind(C, name="spdy_output_batch_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, vor, div, t, q, phi, ps, u_out, v_out, t_out, q_out, phi_out, ps_out
             integer(c_int) :: rc
         end function
     end interface
