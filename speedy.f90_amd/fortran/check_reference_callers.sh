@@ -19,7 +19,7 @@ cd "$TMP"
       "$HERE/spdy_c.f90" "$HERE/spectral.f90" "$HERE/horizontal_diffusion.f90" "$HERE/implicit.f90" "$HERE/geopotential.f90"
 # time_stepping: the reference's dynamical_constants; its prognostics module pulls in the NetCDF chain, so the array
 # declarations come from the stand-in (same names and shapes as prognostics.f90:16-24)
-"$FC" -c -w "$REF/dynamical_constants.f90" "$HERE/support/host_prognostics.f90" "$HERE/time_stepping.f90"
+"$FC" -c -w -cpp "$REF/dynamical_constants.f90" "$HERE/support/host_prognostics.f90" "$HERE/time_stepping.f90"
 echo "drop-ins compile against the reference's types/params"
 "$FC" -c -w "$REF/diagnostics.f90" "$REF/sppt.f90"
 echo "reference callers diagnostics.f90, sppt.f90 compile unchanged against the drop-in spectral.mod"

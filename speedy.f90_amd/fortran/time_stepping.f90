@@ -14,6 +14,12 @@
 !  arithmetic, no PCIe traffic.  Results agree with the reference's call-by-call sequence to 1e-12
 !  (tests/test_fortran_dropin.py, the time_stepping case).
 !
+!  With -DSPDY_WITH_PHYSICS the module is a drop-in for the FULL step(): between the grid-space dynamical tendencies and the
+!  direct transforms it calls the model's own physics%get_physical_tendencies exactly as tendencies.f90:203-206 does -- phi of
+!  time level 1, the level-1 prognostics and the four grid tendencies utend, vtend, ttend, trtend come down to the host arrays,
+!  the physics adds to the tendencies, they go back up -- so the column physics stays the model's Fortran on the host and
+!  everything spectral stays on the GPU.  A step is then plain launches with one host section (no graph).
+!
 !  The host arrays of `prognostics` are uploaded at the first step (or by prognostics_to_device, after the model changed
 !  them) and are NOT kept current: call prognostics_from_device before reading vor, div, t, ps, tr, phi on the host
 !  (output, diagnostics, restart files).  tcorh/qcorh (horizontal_diffusion, filled by forcing.f90) and phis travel with
@@ -79,6 +85,12 @@ contains
             eps = rob
         end if
 
+#ifdef SPDY_WITH_PHYSICS
+        call enqueue_to_grid(j2)
+        call host_physics
+        call enqueue_from_grid(j1, dt, eps)
+        return
+#endif
         if (j1 /= 2) then                 ! the two start-up steps run once: plain launches
             call enqueue_step(j1, j2, dt, eps)
             return
@@ -99,11 +111,16 @@ contains
 
     !> One adiabatic step on the plan's stream (returns when it is queued).
     subroutine enqueue_step(j1, j2, dt, eps)
-        use dynamical_constants, only: tdrs
         integer, intent(in) :: j1, j2
         real(p), intent(in) :: dt, eps
+        call enqueue_to_grid(j2)
+        call enqueue_from_grid(j1, dt, eps)
+    end subroutine
+
+    !> First half: everything of time level j2 to the grid and the grid-space dynamical tendencies.
+    subroutine enqueue_to_grid(j2)
+        integer, intent(in) :: j2
         type(spdy_spec_seg) :: segs(4)
-        real(p) :: sdrag
         integer(c_size_t) :: lev3, lev2
 
         lev3 = (j2 - 1)*kx*spec_bytes            ! time level j2 of an (mx,nx,kx,2) array
@@ -118,11 +135,51 @@ contains
             & 'inverse_batch_segs_dev')
         call spdy_check(spdy_grid_tendencies_dev(spectral_plan, d_ug, d_vg, at(d_plain, 2*kx*grid_bytes), d_plain, &
             & at(d_plain, kx*grid_bytes), at(d_plain, 3*kx*grid_bytes), d_px, d_py, d_u, d_v, d_pl), 'grid_tendencies_dev')
+    end subroutine
+
+    !> Second half: direct transforms, spectral tendencies, implicit correction, diffusion, leapfrog.
+    subroutine enqueue_from_grid(j1, dt, eps)
+        use dynamical_constants, only: tdrs
+        integer, intent(in) :: j1
+        real(p), intent(in) :: dt, eps
+        real(p) :: sdrag
+
         sdrag = 1.0/(tdrs*3600.0)                ! time_stepping.f90:77
         call spdy_check(spdy_direct_batch_spectral_step_dev(spectral_plan, d_u, d_v, d_pl, 2_c_int, d_pvor, d_pdiv, d_pspec, &
             & d_vor, d_div, d_t, d_tr, d_ps, d_phis, d_tcorh, d_qcorh, sdrag, int(j1, c_int), dt, eps, wil, d_phi), &
             & 'direct_batch_spectral_step_dev')
     end subroutine
+
+#ifdef SPDY_WITH_PHYSICS
+    !> tendencies.f90:203-206 with the model's own physics on the host: phi = get_geopotential(t(:,:,:,1), phis), then
+    !  get_physical_tendencies(vor(:,:,:,1), div(:,:,:,1), t(:,:,:,1), tr(:,:,:,1,1), phi, ps(:,:,1), utend, vtend, ttend, trtend)
+    !  adds to the dynamical grid tendencies, which sit in the operands of the direct batch: utend = U(1:kx), vtend = V(1:kx),
+    !  ttend = PL(kx+1:2kx), trtend = PL(2kx+1:3kx)  (include/spdy.h, spdy_grid_tendencies_dev).
+    subroutine host_physics
+        use prognostics, only: vor, div, t, ps, tr, phi
+        use physics, only: get_physical_tendencies
+        real(p), allocatable, save :: utend(:,:,:), vtend(:,:,:), ttend(:,:,:), trtend(:,:,:)
+
+        if (.not. allocated(utend)) allocate(utend(ix,il,kx), vtend(ix,il,kx), ttend(ix,il,kx), trtend(ix,il,kx))
+        call spdy_check(spdy_geopotential_dev(spectral_plan, d_t, d_phis, d_phi), 'geopotential_dev')
+        ! time level 1 is the leading half of every prognostic array
+        call spdy_check(spdy_dev_download(spectral_plan, vor, d_vor, kx*spec_bytes), 'download vor(1)')
+        call spdy_check(spdy_dev_download(spectral_plan, div, d_div, kx*spec_bytes), 'download div(1)')
+        call spdy_check(spdy_dev_download(spectral_plan, t, d_t, kx*spec_bytes), 'download t(1)')
+        call spdy_check(spdy_dev_download(spectral_plan, tr, d_tr, kx*spec_bytes), 'download tr(1)')
+        call spdy_check(spdy_dev_download(spectral_plan, ps, d_ps, spec_bytes), 'download ps(1)')
+        call spdy_check(spdy_dev_download(spectral_plan, phi, d_phi, kx*spec_bytes), 'download phi')
+        call spdy_check(spdy_dev_download(spectral_plan, utend, d_u, kx*grid_bytes), 'download utend')
+        call spdy_check(spdy_dev_download(spectral_plan, vtend, d_v, kx*grid_bytes), 'download vtend')
+        call spdy_check(spdy_dev_download(spectral_plan, ttend, at(d_pl, kx*grid_bytes), kx*grid_bytes), 'download ttend')
+        call spdy_check(spdy_dev_download(spectral_plan, trtend, at(d_pl, 2*kx*grid_bytes), kx*grid_bytes), 'download trtend')
+        call get_physical_tendencies(vor(:,:,:,1), div(:,:,:,1), t(:,:,:,1), tr(:,:,:,1,1), phi, ps(:,:,1), utend, vtend, ttend, trtend)
+        call spdy_check(spdy_dev_upload(spectral_plan, d_u, utend, kx*grid_bytes), 'upload utend')
+        call spdy_check(spdy_dev_upload(spectral_plan, d_v, vtend, kx*grid_bytes), 'upload vtend')
+        call spdy_check(spdy_dev_upload(spectral_plan, at(d_pl, kx*grid_bytes), ttend, kx*grid_bytes), 'upload ttend')
+        call spdy_check(spdy_dev_upload(spectral_plan, at(d_pl, 2*kx*grid_bytes), trtend, kx*grid_bytes), 'upload trtend')
+    end subroutine
+#endif
 
     !> Host arrays of `prognostics` (and phis, tcorh, qcorh) -> HBM; allocates the device state on first use.
     subroutine prognostics_to_device

@@ -153,16 +153,34 @@ def test_dropin_module_vs_oracle(tag, tmp_path, oracle_factory):
     assert pos[0] == raw.size
 
 
+def standin_physics(o, st, utend, vtend, ttend, trtend):
+    """support/host_physics.f90 restated: the linear terms the stand-in `physics` module adds (time level 1 of the prognostics,
+    phi = get_geopotential(t(:,:,:,1), phis) as tendencies.f90:203)."""
+    phi = o.geopotential(st["t"][0], st["phis"])
+    pslg = o.spec_to_grid(st["ps"][0], 1)
+    for k in range(o.kx):
+        utend[k] = utend[k] + 1.0e-9 * o.spec_to_grid(phi[k], 1)
+        vtend[k] = 0.999 * vtend[k] + 1.0e-3 * o.spec_to_grid(st["vor"][0, k], 1)
+        ttend[k] = ttend[k] - 1.0e-6 * (o.spec_to_grid(st["t"][0, k], 1) - 250.0)
+        g = o.spec_to_grid(st["tr"][0, k], 1) + o.spec_to_grid(st["div"][0, k], 1)
+        trtend[k] = trtend[k] + 1.0e-7 * pslg - 1.0e-6 * g
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("phys", [False, True])
 @pytest.mark.parametrize("tag", ["t30", "t63"])
-def test_time_stepping_dropin_vs_oracle(tag, tmp_path, oracle_factory):
+def test_time_stepping_dropin_vs_oracle(tag, phys, tmp_path, oracle_factory):
     """The `time_stepping` drop-in (fortran/time_stepping.f90): a flang-built main loop calls first_step and step(2, 2, 2*delt)
     as the model does (time_stepping.f90:11-24, :35-118 without the column physics); the prognostics stay in HBM, the leapfrog
     step is one captured graph.  After the start-up sequence and after each leapfrog step: both time levels of the five
     prognostics, the geopotential and the tendencies the step applied, against the oracle's call-by-call sequence at 1e-12
-    of each array's maximum, in the plain norm and with the global mean removed."""
+    of each array's maximum, in the plain norm and with the global mean removed.
+
+    phys: the -DSPDY_WITH_PHYSICS build -- step() calls the model's physics%get_physical_tendencies on the host between the grid
+    tendencies and the direct transforms (tendencies.f90:203-206); support/host_physics.f90 stands in for the column physics."""
     from test_gpu_step import ROB, WIL, state, oracle_dynamics_step, wave_relerr
-    exe = os.path.join(FDIR, "build", tag, "dropin_step")
+    exe = os.path.join(FDIR, "build", tag, "dropin_step_phys" if phys else "dropin_step")
+    hook = standin_physics if phys else None
     if not os.path.exists(exe):
         pytest.skip("Fortran driver not built (no flang on this box and no prebuilt binary)")
     o = oracle_factory(tag)
@@ -186,13 +204,13 @@ def test_time_stepping_dropin_vs_oracle(tag, tmp_path, oracle_factory):
 
     delt = float(np.float32(86400.0) / np.float32(36))               # params.f90:31
     # first_step (time_stepping.f90:11-24): forward half step from level 1, leapfrog step without filter, then 2*delt
-    o.tail_init(0.5 * delt); ref, _ = oracle_dynamics_step(o, st, 1, 0.5 * delt, 0.0, j2=1)
-    o.tail_init(delt); ref, out = oracle_dynamics_step(o, ref, 1, delt, 0.0, j2=2)
+    o.tail_init(0.5 * delt); ref, _ = oracle_dynamics_step(o, st, 1, 0.5 * delt, 0.0, j2=1, physics=hook)
+    o.tail_init(delt); ref, out = oracle_dynamics_step(o, ref, 1, delt, 0.0, j2=2, physics=hook)
     o.tail_init(2 * delt)
     worst = {}
     for rec in range(1 + nleap):
         if rec:
-            ref, out = oracle_dynamics_step(o, ref, 2, 2 * delt, ROB, j2=2)
+            ref, out = oracle_dynamics_step(o, ref, 2, 2 * delt, ROB, j2=2, physics=hook)
         got = {n: take(2, kx, nx, mx) for n in ("vor", "div", "t", "tr")}
         got["ps"], got["phi"] = take(2, nx, mx), take(kx, nx, mx)
         for n in ("vordt", "divdt", "tdt", "trdt"):
@@ -204,4 +222,4 @@ def test_time_stepping_dropin_vs_oracle(tag, tmp_path, oracle_factory):
             worst[n] = max(worst.get(n, 0.0), e)
             assert e <= TOL, (tag, rec, n, e)
     assert pos[0] == raw.size
-    print("\n[time_stepping drop-in %s] worst relative errors: " % tag + " ".join("%s %.1e" % kv for kv in worst.items()))
+    print("\n[time_stepping drop-in %s%s] worst relative errors: " % (tag, " + host physics" if phys else "") + " ".join("%s %.1e" % kv for kv in worst.items()))

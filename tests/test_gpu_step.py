@@ -252,7 +252,7 @@ def test_output_path(tag, oracle_factory):
     g.close(); sp.close()
 
 
-def oracle_dynamics_step(o, st, j1, dt, eps, j2=2):
+def oracle_dynamics_step(o, st, j1, dt, eps, j2=2, physics=None):
     """One adiabatic time step of the dynamical core on the host, the reference's own call sequence (tendencies.f90:11-41,
     time_stepping.f90:35-118 without get_physical_tendencies): inverse transforms of time level j2, grid-space
     tendencies, direct transforms, spectral tendencies, implicit correction, diffusion, leapfrog/RAW."""
@@ -267,6 +267,9 @@ def oracle_dynamics_step(o, st, j1, dt, eps, j2=2):
     px, py = o.spec_to_grid(dx, 2), o.spec_to_grid(dy, 2)
     U, V, PL = o.grid_tendencies(ug, vg, tg, vorg, divg, trg, px, py)
     P = 3 * kx
+    if physics is not None:          # tendencies.f90:203-206: the physics adds to utend, vtend, ttend, trtend in grid space
+        U, V, PL = np.array(U, copy=True), np.array(V, copy=True), np.array(PL, copy=True)
+        physics(o, st, U[:kx], V[:kx], PL[kx:2 * kx], PL[2 * kx:3 * kx])
     vd = [o.vdspec(U[i], V[i], 2) for i in range(P)]
     pvor, pdiv = np.stack([x[0] for x in vd]), np.stack([x[1] for x in vd])
     pspec = np.stack([o.grid_to_spec(PL[i]) for i in range(P + 1)])
