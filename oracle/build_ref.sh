@@ -51,8 +51,20 @@ build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock), $3 = o
         sed -n '/^    function step_field_3d/,/^end module/p' "$REF/time_stepping.f90" | sed '$d'
         echo "end module"; } > "$tmp/step_field_ref.f90"
     grep -q "function step_field_2d" "$tmp/step_field_ref.f90" || { echo "build_ref: step_field extraction failed"; exit 1; }
+    # get_spectral_tendencies (tendencies.f90:241-293) the same way: its module also holds get_grid_point_tendencies, which
+    # drags physics -> ... -> NetCDF, and it reads the prognostic arrays of module `prognostics`, whose initialisation routines
+    # drag boundaries / input_output.  Both are cut out of the reference files AS THEY ARE: the subroutine by its own first and
+    # last lines, and the DECLARATION PART of prognostics.f90 (everything before `contains`: prognostics.f90:4-24) minus the
+    # one `public initialize_prognostics` line, whose procedure stays behind.  No statement is written or changed here.
+    {   sed -n '/^module prognostics/,/^contains/p' "$REF/prognostics.f90" | sed -e '$d' -e '/public initialize_prognostics/d'
+        echo "end module"; } > "$tmp/prognostics_decl.f90"
+    {   echo "module spectral_tendencies_ref"; echo "    use types, only: p"; echo "    use params"; echo "    implicit none"; echo "contains"
+        sed -n '/^    subroutine get_spectral_tendencies/,/^    end subroutine/p' "$REF/tendencies.f90"
+        echo "end module"; } > "$tmp/spectral_tendencies_ref.f90"
+    grep -q "complex(p) :: phis(mx,nx)" "$tmp/prognostics_decl.f90" && grep -q "laplacian(phi(:,:,k) + rgas\*tref(k)\*ps(:,:,j2))" "$tmp/spectral_tendencies_ref.f90" \
+        || { echo "build_ref: get_spectral_tendencies extraction failed"; exit 1; }
     ( cd "$tmp" && "$FC" $opt -fPIC -shared -w -Wl,-Bsymbolic -o "$OUT/libspeedy_ref_${tag}.so" \
-          "${srcs[@]}" "$tmp/step_field_ref.f90" "$HERE/ref_shim.f90" )
+          "${srcs[@]}" "$tmp/step_field_ref.f90" "$tmp/prognostics_decl.f90" "$tmp/spectral_tendencies_ref.f90" "$HERE/ref_shim.f90" )
     rm -rf "$tmp"
     echo "build_ref: built $OUT/libspeedy_ref_${tag}.so"
 }

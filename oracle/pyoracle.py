@@ -364,6 +364,15 @@ class Reference(_Dims):
         fn(ctypes.c_int(j1), ctypes.c_double(dt), ctypes.c_double(eps), _ptr(f), _ptr(d))
         return f, d
 
+    def spectral_tendencies(self, div, t, ps, phis, divdt, tdt, psdt, j2=1):
+        """tendencies.f90:241-293 compiled from the reference file (build_ref.sh); div, t, ps: the time-level-j2 slabs.  Returns
+        updated copies (divdt, tdt, psdt, phi).  Call tail_init first."""
+        ins = [_c128(x) for x in (div, t, ps, phis)]
+        outs = [_c128(x).copy() for x in (divdt, tdt, psdt)]
+        phi = np.zeros_like(ins[1])
+        self.lib.ref_spectral_tendencies(ctypes.c_int(j2), *[_ptr(x) for x in ins], *[_ptr(x) for x in outs], _ptr(phi))
+        return outs[0], outs[1], outs[2], phi
+
     def roundtrip_loop(self, g_in, nrep=1):
         g_in = _f64(g_in); out = np.empty_like(g_in)
         self.lib.ref_roundtrip_loop(ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))

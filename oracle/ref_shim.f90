@@ -380,3 +380,26 @@ subroutine ref_get_wil_rob(o_wil, o_rob) bind(C, name="ref_get_wil_rob")
     o_wil = wil
     o_rob = rob
 end subroutine
+
+! tendencies.f90:241-293 get_spectral_tendencies, compiled from the reference file itself (build_ref.sh cuts the subroutine
+! into the scratch module spectral_tendencies_ref and the declaration part of prognostics.f90 into module prognostics).  The
+! time-level-j2 slabs of div, t, ps and phis are assigned to the reference's own module arrays; phi is read back from them.
+! Needs ref_tail_init (tref, tref2, tref3 of implicit) first, like the model (time_stepping.f90:14).
+subroutine ref_spectral_tendencies(j2, i_div, i_t, i_ps, i_phis, divdt, tdt, psdt, o_phi) bind(C, name="ref_spectral_tendencies")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use prognostics, only: div, t, ps, phis, phi
+    use geopotential, only: initialize_geopotential
+    use spectral_tendencies_ref, only: get_spectral_tendencies
+    integer(c_int), value :: j2
+    complex(c_double_complex), intent(in) :: i_div(mx,nx,kx), i_t(mx,nx,kx), i_ps(mx,nx), i_phis(mx,nx)
+    complex(c_double_complex), intent(inout) :: divdt(mx,nx,kx), tdt(mx,nx,kx), psdt(mx,nx)
+    complex(c_double_complex), intent(out) :: o_phi(mx,nx,kx)
+    call initialize_geopotential
+    div(:,:,:,j2) = i_div
+    t(:,:,:,j2) = i_t
+    ps(:,:,j2) = i_ps
+    phis = i_phis
+    call get_spectral_tendencies(divdt, tdt, psdt, int(j2))
+    o_phi = phi
+end subroutine

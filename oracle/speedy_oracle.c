@@ -996,9 +996,10 @@ ORC_API void orc_geopotential(const orc_ctx *c, const double *t, const double *p
 }
 
 /* ------------------------------------------------------------------ tendencies.f90:242-293 get_spectral_tendencies
- * PARITY UNPINNED: tendencies.f90 cannot be compiled here (it uses prognostics -> boundaries/input_output -> netcdf),
- * so this routine is a reading of the source that no reference build has confirmed.  (get_geopotential inside it IS
- * pinned.)  div, t, ps: time level j2 of the prognostics.                                                           */
+ * PINNED since round 3: tendencies.f90 as a whole cannot be compiled here (get_grid_point_tendencies uses physics -> ... ->
+ * netcdf), but this subroutine, cut out of the reference file as it is together with the declaration part of
+ * prognostics.f90 (oracle/build_ref.sh), compiles with flang; tests/golden/ref_spectend.npz holds its outputs at 8, 5 and
+ * 16 levels (tests/test_oracle_golden.py::test_spectral_tendencies_pinned).  div, t, ps: time level j2 of the prognostics. */
 ORC_API void orc_spectral_tendencies(const orc_ctx *c, const double *div, const double *t, const double *ps, const double *phis,
                                      double *divdt, double *tdt, double *psdt, double *phi)
 {
@@ -1062,7 +1063,8 @@ ORC_API void orc_hdiff_step(const orc_ctx *c, const double *vor, const double *d
 }
 
 /* ------------------------------------------------------------------ time_stepping.f90:121-167 step_field_2d / _3d
- * PARITY UNPINNED (see above).  field(mx,nx,nlev,2): both time levels; fdt(mx,nx,nlev) truncated in place (:155-157). */
+ * PINNED since round 3 (the two functions, cut out of time_stepping.f90 as they are, compile with flang: tests/golden/
+ * ref_step.npz, test_step_field_pinned).  field(mx,nx,nlev,2): both time levels; fdt(mx,nx,nlev) truncated in place (:155-157). */
 ORC_API void orc_step_field(const orc_ctx *c, int nlev, int j1, double dt, double eps, double wil, double *field, double *fdt)
 {
     const int sz = c->mx * c->nx;

@@ -101,6 +101,41 @@ def make_step():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+def spectend_inputs(kx, nx, mx):
+    """Seeded inputs of get_spectral_tendencies: div, t [kx,nx,mx], ps, phis [nx,mx] (one time level) and the tendencies
+    divdt, tdt [kx,nx,mx], psdt [nx,mx] it updates -- magnitudes of the model's fields."""
+    return (synth.cfield((kx, nx, mx), 21, 1e-5), synth.cfield((kx, nx, mx), 22, 30.0), synth.cfield((nx, mx), 23, 0.05),
+            synth.cfield((nx, mx), 24, 2000.0), synth.cfield((kx, nx, mx), 25, 1e-9), synth.cfield((kx, nx, mx), 26, 1e-3),
+            synth.cfield((nx, mx), 27, 1e-7))
+
+
+def make_spectend():
+    """ref_spectend.npz: get_spectral_tendencies (tendencies.f90:241-293) of the flang-built reference -- the subroutine cut out
+    of the reference file by oracle/build_ref.sh -- at 8, 5 and 16 levels, j2 = 1 and 2 (the time level only selects the slab of
+    the reference's prognostic arrays the inputs are put into)."""
+    from oracle.pyoracle import Oracle
+    d = {}
+    for tag, sub in (("t30", None), ("t30k5", None), ("t63k16", L16_SUB)):
+        r = Reference(tag)
+        kx, nx, mx = r.kx, r.nx, r.mx
+        cut = (lambda a, sub=sub: a[sub]) if sub else (lambda a: a)
+        if tag == "t63k16":
+            o = Oracle(r.trunc, r.ix, r.iy, kx)
+            o.set_sigma(synth.SIGMA_L16)
+            r.set_sigma(*[o.table(n) for n in ("hsg", "dhs", "fsg", "dhsr", "fsgr")])
+        r.tail_init(4800.0)
+        div, t, ps, phis, divdt, tdt, psdt = spectend_inputs(kx, nx, mx)
+        for j2 in (1, 2):
+            a, b, c, phi = r.spectral_tendencies(div, t, ps, phis, divdt, tdt, psdt, j2=j2)
+            key = "%s_j%d_" % (tag, j2)
+            if j2 == 2 and sub is None:                   # the second slab must give the same numbers: a sub-lattice is enough
+                cut = lambda a: a[STEP_SUB]
+            d[key + "divdt"], d[key + "tdt"], d[key + "psdt"], d[key + "phi"] = cut(a), cut(b), c, cut(phi)
+    out = os.path.join(HERE, "ref_spectend.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
 def make(tag, nb_grid, dts, imp_dts, lean):
     r = Reference(tag)
     tr, ix, il, kx, nx, mx = r.trunc, r.ix, r.il, r.kx, r.nx, r.mx
@@ -166,7 +201,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "step":      # only the step_field fixture
         make_step()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "spectend":  # only the get_spectral_tendencies fixture
+        make_spectend()
+        sys.exit(0)
     make("t30", nb_grid=2, dts=DTS, imp_dts=(1200.0, 4800.0), lean=False)
     make("t63", nb_grid=1, dts=(4800.0,), imp_dts=(4800.0,), lean=True)
     make_extra()
     make_step()
+    make_spectend()

@@ -240,10 +240,49 @@ def test_step_field_live(oracle_factory):
             close(a, ra); assert np.array_equal(b, rb)
 
 
+SPECTEND_CASES = {"t30": None, "t30k5": None, "t63k16": (slice(None), slice(None, None, 5), slice(None, None, 3))}
+
+
+@pytest.mark.parametrize("tag", sorted(SPECTEND_CASES))
+def test_spectral_tendencies_pinned(tag, oracle_factory):
+    """get_spectral_tendencies (tendencies.f90:241-293): the C oracle against the reference's own subroutine, compiled by flang
+    from the reference file (oracle/build_ref.sh cuts it, and the declaration part of prognostics.f90, into scratch modules) --
+    golden vectors at 8, 5 and 16 levels, the inputs placed in time level 1 and in time level 2 of the reference's arrays."""
+    from golden.make_golden import spectend_inputs
+    z, o = np.load(os.path.join(GOLDEN, "ref_spectend.npz")), oracle_factory(tag)
+    o.tail_init(4800.0)
+    div, t, ps, phis, divdt, tdt, psdt = spectend_inputs(o.kx, o.nx, o.mx)
+    a, b, c, phi = o.spectral_tendencies(div, t, ps, phis, divdt, tdt, psdt)
+    for j2 in (1, 2):
+        sub = SPECTEND_CASES[tag] or (STEP_J1_SUB if j2 == 2 else None)
+        cut = (lambda x: x[sub]) if sub else (lambda x: x)
+        key = "%s_j%d_" % (tag, j2)
+        for mine, name in ((cut(a), "divdt"), (cut(b), "tdt"), (c, "psdt"), (cut(phi), "phi")):
+            ref = z[key + name]
+            assert mine.shape == ref.shape, (name, mine.shape, ref.shape)
+            close(mine, ref)
+
+
+def test_spectral_tendencies_live(oracle_factory):
+    """The same against the live flang build, full arrays and another dt (build container only)."""
+    from oracle.pyoracle import Reference
+    from golden.make_golden import spectend_inputs
+    if not Reference.available("t30"):
+        pytest.skip("oracle/_ref not built")
+    r, o = Reference("t30"), oracle_factory("t30")
+    if not hasattr(r.lib, "ref_spectral_tendencies"):
+        pytest.skip("oracle/_ref predates the get_spectral_tendencies extraction")
+    for dt in (1200.0, 4800.0):
+        r.tail_init(dt); o.tail_init(dt)
+        ins = spectend_inputs(o.kx, o.nx, o.mx)
+        for x, y in zip(o.spectral_tendencies(*ins), r.spectral_tendencies(*ins, j2=2)):
+            close(x, y)
+
+
 def test_step_restatements_selfconsistent(oracle_factory):
-    """get_spectral_tendencies and the diffusion block cannot be pinned (their modules need NetCDF; step_field IS pinned,
-    test_step_field_pinned above): check the restatements against independent NumPy readings of the same source lines, and
-    against the pinned pieces they are built from."""
+    """The diffusion block of step() cannot be pinned (it is inline in a subroutine that needs NetCDF to compile; step_field and
+    get_spectral_tendencies ARE pinned, tests above): check the restatements against independent NumPy readings of the same
+    source lines, and against the pinned pieces they are built from."""
     o = oracle_factory("t30")
     o.tail_init(4800.0)
     kx, nx, mx = o.kx, o.nx, o.mx
