@@ -107,6 +107,34 @@ def cpu_baseline(res, variant="", sample_fields=256, target_s=8.0):
                       "time), %.1f s on one core" % (nrep, sample_fields, res.upper(), dt)}
 
 
+def cpu_step_baseline(tag, target_s=3.0):
+    """The reference's own adiabatic time step on one host core: time_stepping.f90 step(2, 2, 2*delt), compiled by flang -O2
+    unchanged on tendencies.f90 minus its three physics lines (oracle/build_ref.sh), on the seeded state of tests/dynstep.py.
+    tag: a build of oracle/_ref ("t30" = T30 L8, "t63k16" = T63 L16)."""
+    import synth, dynstep
+    from oracle.pyoracle import Oracle, Reference
+    if not Reference.available(tag):
+        return None
+    r = Reference(tag)
+    if not hasattr(r.lib, "ref_step"):
+        return None
+    o = Oracle(r.trunc, r.ix, r.iy, r.kx)
+    if tag in synth.SIGMA_SETS:
+        o.set_sigma(synth.SIGMA_SETS[tag])
+        r.set_sigma(*[o.table(n) for n in ("hsg", "dhs", "fsg", "dhsr", "fsgr")])
+    st = dynstep.state(o, 8000)
+    dt = 4800.0
+    r.tail_init(dt)
+    r.step(2, 2, dt, st)
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or time.perf_counter() - t0 < target_s:
+        r.step(2, 2, dt, st)              # (always from the same state: a random state is not a stable atmosphere)
+        n += 1
+    ms = (time.perf_counter() - t0) * 1e3 / n
+    return {"ms_per_step": ms, "steps": n, "cores": 1, "kind": "reference", "build": "flang -O2",
+            "what": "time_stepping.f90 step(2, 2, dt) without get_physical_tendencies, %s L%d" % (tag[:3].upper(), r.kx)}
+
+
 def cpu_baseline_socket(res, variant="fast", fields=64, target_s=4.0):
     """The same single-threaded reference loop on every physical core of ONE socket at once: one pinned PROCESS per core
     (oracle/cpu_worker.py), each transforming its own fields one at a time for ~target_s seconds.  This is the
@@ -244,6 +272,11 @@ def extras(s, torch, synth, sp, dev, args):
     for tag, res_, kx_ in (("dynamics_step_t30_l8", "t30", 8), ("dynamics_step_t63_l16", "t63", 16)):
         try:
             out[tag] = dynamics_step_time(s, torch, synth, res_, kx_, dev)
+            if not args.no_cpu_baseline:      # the reference's own step() timed on one host core beside it
+                cb = cpu_step_baseline("t30" if kx_ == 8 else "t63k16")
+                if cb:
+                    out[tag]["cpu_reference_step"] = cb
+                    out[tag]["gpu_over_cpu_core"] = cb["ms_per_step"] * 1e3 / out[tag]["us_per_step"]
         except Exception as e:
             out[tag] = {"error": repr(e)}
     # the other BASELINE resolution, same definition of a round trip (config 4: T63, B = 1536)

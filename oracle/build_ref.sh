@@ -63,8 +63,20 @@ build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock), $3 = o
         echo "end module"; } > "$tmp/spectral_tendencies_ref.f90"
     grep -q "complex(p) :: phis(mx,nx)" "$tmp/prognostics_decl.f90" && grep -q "laplacian(phi(:,:,k) + rgas\*tref(k)\*ps(:,:,j2))" "$tmp/spectral_tendencies_ref.f90" \
         || { echo "build_ref: get_spectral_tendencies extraction failed"; exit 1; }
+    # The reference's whole time step, ADIABATIC: with the declaration part of prognostics.f90 in place, tendencies.f90 needs
+    # nothing that is missing here except the column physics (physics -> ... -> NetCDF).  The scratch copy of tendencies.f90
+    # has exactly the three physics lines deleted -- the `use physics` line and the two-line `call get_physical_tendencies`
+    # (tendencies.f90:55, :205-206) -- i.e. it is the reference's get_tendencies with T_phy = 0; time_stepping.f90 (first_step,
+    # step, and the diffusion block inside it) then compiles FROM THE REFERENCE FILE, unchanged.
+    sed -e '/use physics, only: get_physical_tendencies/d' \
+        -e '/call get_physical_tendencies(/,/utend, vtend, ttend, trtend)/d' "$REF/tendencies.f90" > "$tmp/tendencies.f90"
+    if grep -q "get_physical_tendencies" "$tmp/tendencies.f90" || ! grep -q "phi = get_geopotential(t(:,:,:,j1), phis)" "$tmp/tendencies.f90" \
+       || [ "$(wc -l < "$REF/tendencies.f90")" -ne "$(( $(wc -l < "$tmp/tendencies.f90") + 3 ))" ]; then
+        echo "build_ref: adiabatic tendencies.f90 is not the reference minus its three physics lines"; exit 1
+    fi
     ( cd "$tmp" && "$FC" $opt -fPIC -shared -w -Wl,-Bsymbolic -o "$OUT/libspeedy_ref_${tag}.so" \
-          "${srcs[@]}" "$tmp/step_field_ref.f90" "$tmp/prognostics_decl.f90" "$tmp/spectral_tendencies_ref.f90" "$HERE/ref_shim.f90" )
+          "${srcs[@]}" "$tmp/step_field_ref.f90" "$tmp/prognostics_decl.f90" "$tmp/spectral_tendencies_ref.f90" \
+          "$tmp/tendencies.f90" "$REF/time_stepping.f90" "$HERE/ref_shim.f90" )
     rm -rf "$tmp"
     echo "build_ref: built $OUT/libspeedy_ref_${tag}.so"
 }

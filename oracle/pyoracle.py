@@ -373,6 +373,43 @@ class Reference(_Dims):
         self.lib.ref_spectral_tendencies(ctypes.c_int(j2), *[_ptr(x) for x in ins], *[_ptr(x) for x in outs], _ptr(phi))
         return outs[0], outs[1], outs[2], phi
 
+    def step(self, j1, j2, dt, st):
+        """One ADIABATIC time step of the reference: time_stepping.f90:35-118 step(j1, j2, dt), the reference file compiled
+        unchanged on top of tendencies.f90 minus its three physics lines (build_ref.sh).  st: dict with vor, div, t, tr
+        [2, kx, nx, mx], ps [2, nx, mx], phis, tcorh, qcorh [nx, mx]; returns (new state dict, phi).  Call tail_init(dt) first.
+        Runs on a thread with a large stack: the reference keeps its work arrays (tens of MB at T63 L16) on the stack."""
+        import threading
+        new = {k: _c128(st[k]).copy() for k in ("vor", "div", "t", "tr", "ps")}
+        fixed = {k: _c128(st[k]) for k in ("phis", "tcorh", "qcorh")}
+        phi = np.zeros((self.kx,) + self.spec_shape, np.complex128)
+
+        def run():
+            self.lib.ref_step(ctypes.c_int(j1), ctypes.c_int(j2), ctypes.c_double(dt), *[_ptr(new[k]) for k in ("vor", "div", "t", "tr", "ps")],
+                              *[_ptr(fixed[k]) for k in ("phis", "tcorh", "qcorh")], _ptr(phi))
+        old = threading.stack_size(1 << 30)
+        try:
+            th = threading.Thread(target=run); th.start(); th.join()
+        finally:
+            threading.stack_size(old)
+        return dict(st, **new), phi
+
+    def get_tendencies(self, j2, st):
+        """tendencies.f90:11-41 get_tendencies of the same adiabatic build -> (vordt, divdt, tdt, psdt, trdt)."""
+        import threading
+        ins = [_c128(st[k]) for k in ("vor", "div", "t", "tr", "ps", "phis")]
+        sh = (self.kx,) + self.spec_shape
+        outs = [np.zeros(sh, np.complex128), np.zeros(sh, np.complex128), np.zeros(sh, np.complex128),
+                np.zeros(self.spec_shape, np.complex128), np.zeros(sh, np.complex128)]
+
+        def run():
+            self.lib.ref_get_tendencies(ctypes.c_int(j2), *[_ptr(x) for x in ins], *[_ptr(x) for x in outs])
+        old = threading.stack_size(1 << 30)
+        try:
+            th = threading.Thread(target=run); th.start(); th.join()
+        finally:
+            threading.stack_size(old)
+        return tuple(outs)
+
     def roundtrip_loop(self, g_in, nrep=1):
         g_in = _f64(g_in); out = np.empty_like(g_in)
         self.lib.ref_roundtrip_loop(ctypes.c_int(g_in.shape[0]), ctypes.c_int(nrep), _ptr(g_in), _ptr(out))

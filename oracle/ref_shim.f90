@@ -403,3 +403,61 @@ subroutine ref_spectral_tendencies(j2, i_div, i_t, i_ps, i_phis, divdt, tdt, psd
     call get_spectral_tendencies(divdt, tdt, psdt, int(j2))
     o_phi = phi
 end subroutine
+
+! time_stepping.f90:35-118 step(j1, j2, dt) -- the reference file itself, compiled unchanged -- on top of the reference's
+! tendencies.f90 minus its three physics lines (build_ref.sh): one ADIABATIC time step of the reference.  The prognostics
+! (both time levels), phis and the orographic-correction fields tcorh / qcorh are assigned to the reference's own public
+! module variables; the stepped prognostics and phi are read back from them.  Needs ref_tail_init(dt) first
+! (initialize_horizontal_diffusion + initialize_implicit, as time_stepping.f90:12-24 / initialization.f90:20 do).
+subroutine ref_step(j1, j2, dt, io_vor, io_div, io_t, io_tr, io_ps, i_phis, i_tcorh, i_qcorh, o_phi) bind(C, name="ref_step")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use prognostics, only: vor, div, t, tr, ps, phis, phi
+    use horizontal_diffusion, only: tcorh, qcorh
+    use geopotential, only: initialize_geopotential
+    use time_stepping, only: step
+    integer(c_int), value :: j1, j2
+    real(c_double), value :: dt
+    complex(c_double_complex), intent(inout) :: io_vor(mx,nx,kx,2), io_div(mx,nx,kx,2), io_t(mx,nx,kx,2), io_tr(mx,nx,kx,2), io_ps(mx,nx,2)
+    complex(c_double_complex), intent(in) :: i_phis(mx,nx), i_tcorh(mx,nx), i_qcorh(mx,nx)
+    complex(c_double_complex), intent(out) :: o_phi(mx,nx,kx)
+    call initialize_geopotential
+    vor = io_vor
+    div = io_div
+    t = io_t
+    tr(:,:,:,:,1) = io_tr
+    ps = io_ps
+    phis = i_phis
+    tcorh = i_tcorh
+    qcorh = i_qcorh
+    call step(int(j1), int(j2), dt)
+    io_vor = vor
+    io_div = div
+    io_t = t
+    io_tr = tr(:,:,:,:,1)
+    io_ps = ps
+    o_phi = phi
+end subroutine
+
+! tendencies.f90:11-41 get_tendencies (same adiabatic build): the spectral tendencies of one step before the diffusion and the
+! time integration -- transforms of time level j2, grid-space dynamical tendencies, direct transforms, get_spectral_tendencies
+! and implicit_terms (alph = 0.5).
+subroutine ref_get_tendencies(j2, i_vor, i_div, i_t, i_tr, i_ps, i_phis, vordt, divdt, tdt, psdt, trdt) bind(C, name="ref_get_tendencies")
+    use iso_c_binding
+    use params, only: mx, nx, kx
+    use prognostics, only: vor, div, t, tr, ps, phis
+    use geopotential, only: initialize_geopotential
+    use tendencies, only: get_tendencies
+    integer(c_int), value :: j2
+    complex(c_double_complex), intent(in) :: i_vor(mx,nx,kx,2), i_div(mx,nx,kx,2), i_t(mx,nx,kx,2), i_tr(mx,nx,kx,2), i_ps(mx,nx,2), i_phis(mx,nx)
+    complex(c_double_complex), intent(out) :: vordt(mx,nx,kx), divdt(mx,nx,kx), tdt(mx,nx,kx), psdt(mx,nx), trdt(mx,nx,kx,1)
+    call initialize_geopotential
+    vor = i_vor
+    div = i_div
+    t = i_t
+    tr(:,:,:,:,1) = i_tr
+    ps = i_ps
+    phis = i_phis
+    vordt = (0.0d0, 0.0d0); divdt = (0.0d0, 0.0d0); tdt = (0.0d0, 0.0d0); psdt = (0.0d0, 0.0d0); trdt = (0.0d0, 0.0d0)
+    call get_tendencies(vordt, divdt, tdt, psdt, trdt, int(j2))
+end subroutine

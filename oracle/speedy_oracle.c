@@ -1033,8 +1033,9 @@ ORC_API void orc_spectral_tendencies(const orc_ctx *c, const double *div, const 
 }
 
 /* ------------------------------------------------------------------ time_stepping.f90:62-96: the diffusion block of step()
- * PARITY UNPINNED (time_stepping.f90 uses prognostics/tendencies -> netcdf chain; do_horizontal_diffusion itself is pinned).
- * vor, div, t, tr: time level 1; tcorh, qcorh: (mx,nx) complex; tr/trdt may be NULL.                                */
+ * PINNED since round 3 as part of the whole step: the reference's time_stepping.f90, compiled unchanged on tendencies.f90 minus
+ * its three physics lines (oracle/build_ref.sh), reproduces the sequence this routine is part of bit for bit
+ * (tests/dynstep.py, tests/golden/ref_dynstep.npz, test_dynamics_step_pinned).  vor, div, t, tr: time level 1; tcorh, qcorh: (mx,nx) complex; tr/trdt may be NULL.                                */
 ORC_API void orc_hdiff_step(const orc_ctx *c, const double *vor, const double *div, const double *t, const double *tr,
                             const double *tcorh, const double *qcorh, double sdrag,
                             double *vordt, double *divdt, double *tdt, double *trdt)
@@ -1111,7 +1112,8 @@ ORC_API void orc_output(const orc_ctx *c, const double *vor, const double *div, 
 }
 
 /* ------------------------------------------------------------------ tendencies.f90:105-197: grid-space dynamical tendencies
- * PARITY UNPINNED (tendencies.f90 needs the netcdf chain).  Inputs: gridded prognostics of time level j2 (vorg WITHOUT
+ * PINNED since round 3 as part of the whole step and of get_tendencies (tendencies.f90 minus its three physics lines compiles
+ * with flang: oracle/build_ref.sh; test_dynamics_step_pinned, bit for bit).  Inputs: gridded prognostics of time level j2 (vorg WITHOUT
  * Coriolis: added here as :103-107 does), px, py = spec_to_grid(grad(ps), 2).  Outputs in the layout of the direct batch:
  * u, v [3 kx] = (utend, vtend) | (-ug*tgg, -vg*tgg) | (-ug*trg, -vg*trg); plain [3 kx + 1] = KE | ttend | trtend | psdt grid. */
 ORC_API void orc_grid_tendencies(const orc_ctx *c, const double *ug, const double *vg, const double *tg, const double *vorg_in,

@@ -136,6 +136,39 @@ def make_spectend():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+DYN63_SUB = (slice(None), slice(None, None, 9), slice(None, None, 5))   # the part of a [16,65,64] array kept for the step fixture
+DYNSTEP_CASES = ((1, 1, 1200.0), (2, 2, 4800.0))     # (j1, j2, dt): the forward half step of first_step, the leapfrog step
+
+
+def make_dynstep():
+    """ref_dynstep.npz: one ADIABATIC time step of the flang-built reference -- time_stepping.f90 step(j1, j2, dt), the file
+    compiled unchanged on tendencies.f90 minus its three physics lines (oracle/build_ref.sh) -- from the seeded state of
+    tests/dynstep.py at 8, 5 and 16 levels: both time levels of the five prognostics and phi (sub-lattices of the arrays)."""
+    import dynstep
+    from oracle.pyoracle import Oracle
+    d = {}
+    for tag, sub in (("t30", STEP_SUB), ("t30k5", STEP_SUB), ("t63k16", DYN63_SUB)):
+        r = Reference(tag)
+        o = Oracle(r.trunc, r.ix, r.iy, r.kx)
+        if tag == "t63k16":
+            o.set_sigma(synth.SIGMA_L16)
+            r.set_sigma(*[o.table(n) for n in ("hsg", "dhs", "fsg", "dhsr", "fsgr")])
+        st = dynstep.state(o, 8000)
+        for j1, j2, dt in (DYNSTEP_CASES if tag == "t30" else DYNSTEP_CASES[1:]):
+            r.tail_init(dt)
+            new, phi = r.step(j1, j2, dt, st)
+            key = "%s_j%d%d_" % (tag, j1, j2)
+            for n in ("vor", "div", "t", "tr"):
+                d[key + n] = new[n][(Ellipsis,) + sub[1:]]
+            d[key + "ps"], d[key + "phi"] = new["ps"], phi[sub]
+            vt = r.get_tendencies(j2, st)
+            for n, a in zip(("vordt", "divdt", "tdt", "psdt", "trdt"), vt):
+                d[key + n] = a if n == "psdt" else a[sub]
+    out = os.path.join(HERE, "ref_dynstep.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
 def make(tag, nb_grid, dts, imp_dts, lean):
     r = Reference(tag)
     tr, ix, il, kx, nx, mx = r.trunc, r.ix, r.il, r.kx, r.nx, r.mx
@@ -201,6 +234,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "step":      # only the step_field fixture
         make_step()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dynstep":   # only the adiabatic-step fixture
+        make_dynstep()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "spectend":  # only the get_spectral_tendencies fixture
         make_spectend()
         sys.exit(0)
@@ -209,3 +245,4 @@ if __name__ == "__main__":
     make_extra()
     make_step()
     make_spectend()
+    make_dynstep()

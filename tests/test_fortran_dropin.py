@@ -178,7 +178,7 @@ def test_time_stepping_dropin_vs_oracle(tag, phys, tmp_path, oracle_factory):
 
     phys: the -DSPDY_WITH_PHYSICS build -- step() calls the model's physics%get_physical_tendencies on the host between the grid
     tendencies and the direct transforms (tendencies.f90:203-206); support/host_physics.f90 stands in for the column physics."""
-    from test_gpu_step import ROB, WIL, state, oracle_dynamics_step, wave_relerr
+    from dynstep import ROB, WIL, state, oracle_dynamics_step, wave_relerr
     exe = os.path.join(FDIR, "build", tag, "dropin_step_phys" if phys else "dropin_step")
     hook = standin_physics if phys else None
     if not os.path.exists(exe):

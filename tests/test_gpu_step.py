@@ -4,20 +4,19 @@
 Checker: the C oracle.  implicit_terms, do_horizontal_diffusion, get_geopotential and all transforms/operators in it
 are pinned to flang builds of the reference (also at 16 levels), and since round 3 so is step_field_2d/3d
 (time_stepping.f90:126-167: the two functions compile on their own, oracle/build_ref.sh; test_step_fields_vs_golden).
-get_spectral_tendencies and the diffusion block of step() are restatements of tendencies.f90:242-293 /
-time_stepping.f90:62-96, which cannot be compiled here (NetCDF chain) -- PARITY UNPINNED for those two, cross-checked
-against NumPy readings of the same lines in tests/test_oracle_golden.py::test_step_restatements_selfconsistent (the diffusion
-block is seven calls of the pinned do_horizontal_diffusion)."""
+Since the end of round 3 the WHOLE adiabatic step of the oracle (tests/dynstep.py::oracle_dynamics_step: grid-space tendencies,
+get_spectral_tendencies, the diffusion block of step() included) is pinned bit for bit to the reference's own
+time_stepping.f90 / tendencies.f90 compiled by flang (oracle/build_ref.sh: tendencies.f90 minus its three physics lines;
+tests/test_oracle_golden.py::test_dynamics_step_pinned)."""
 import numpy as np
 import pytest
 
 import synth
 from conftest import TOL, VARIANTS
+from dynstep import ROB, WIL, SDRAG, state, oracle_dynamics_step, wave_relerr
 
 pytestmark = pytest.mark.gpu
 
-ROB, WIL = float(np.float32(0.05)), float(np.float32(0.53))          # params.f90:32-33 (float32 literals widened)
-SDRAG = 1.0 / (float(np.float32(24.0 * 30.0)) * 3600.0)              # time_stepping.f90:77, dynamical_constants.f90:22
 
 
 def ok(x, ref, tol=TOL):
@@ -33,21 +32,6 @@ def make_plan(tag, max_batch):
     if tag in synth.SIGMA_SETS:
         sp.set_sigma(synth.SIGMA_SETS[tag])
     return sp
-
-
-def state(sp, seed):
-    """Band-limited prognostics [2, kx, nx, mx] (both time levels) and a few (nx, mx) fields."""
-    kx, nx, mx = sp.kx, sp.nx, sp.mx
-
-    def prog(first, scale):
-        return (synth.spectra(2 * kx, sp.trunc, first=first) * scale).reshape(2, kx, nx, mx)
-    st = {"vor": prog(seed, 1e-4), "div": prog(seed + 100, 1e-5), "t": prog(seed + 200, 30.0), "tr": prog(seed + 300, 1e-2)}
-    st["t"][:, :, 0, 0] += 250.0 * np.sqrt(2.0)
-    st["ps"] = (synth.spectra(2, sp.trunc, first=seed + 400) * 0.05).reshape(2, nx, mx)
-    st["phis"] = synth.spectra(1, sp.trunc, first=seed + 500)[0] * 2000.0
-    st["tcorh"] = synth.spectra(1, sp.trunc, first=seed + 600)[0] * 5.0
-    st["qcorh"] = synth.spectra(1, sp.trunc, first=seed + 700)[0] * 1e-3
-    return st
 
 
 @pytest.mark.parametrize("tag", ["t30", "t63", "t30k5", "t63k16", "t30k20"])
@@ -250,50 +234,6 @@ def test_output_path(tag, oracle_factory):
     for a, b in zip(outs, outs2):
         assert torch.equal(a, b)
     g.close(); sp.close()
-
-
-def oracle_dynamics_step(o, st, j1, dt, eps, j2=2, physics=None):
-    """One adiabatic time step of the dynamical core on the host, the reference's own call sequence (tendencies.f90:11-41,
-    time_stepping.f90:35-118 without get_physical_tendencies): inverse transforms of time level j2, grid-space
-    tendencies, direct transforms, spectral tendencies, implicit correction, diffusion, leapfrog/RAW."""
-    kx, j2 = o.kx, j2 - 1
-    ug, vg = [], []
-    for k in range(kx):
-        u, v = o.uvspec(st["vor"][j2, k], st["div"][j2, k])
-        ug.append(o.spec_to_grid(u, 2)); vg.append(o.spec_to_grid(v, 2))
-    ug, vg = np.stack(ug), np.stack(vg)
-    vorg, divg, tg, trg = (np.stack([o.spec_to_grid(st[n][j2, k], 1) for k in range(kx)]) for n in ("vor", "div", "t", "tr"))
-    dx, dy = o.grad(st["ps"][j2])
-    px, py = o.spec_to_grid(dx, 2), o.spec_to_grid(dy, 2)
-    U, V, PL = o.grid_tendencies(ug, vg, tg, vorg, divg, trg, px, py)
-    P = 3 * kx
-    if physics is not None:          # tendencies.f90:203-206: the physics adds to utend, vtend, ttend, trtend in grid space
-        U, V, PL = np.array(U, copy=True), np.array(V, copy=True), np.array(PL, copy=True)
-        physics(o, st, U[:kx], V[:kx], PL[kx:2 * kx], PL[2 * kx:3 * kx])
-    vd = [o.vdspec(U[i], V[i], 2) for i in range(P)]
-    pvor, pdiv = np.stack([x[0] for x in vd]), np.stack([x[1] for x in vd])
-    pspec = np.stack([o.grid_to_spec(PL[i]) for i in range(P + 1)])
-    pdiv, pspec = o.tendency_combine(pdiv, pspec)
-    vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[P]
-    divdt, tdt, psdt, phi = o.spectral_tendencies(st["div"][0], st["t"][0], st["ps"][0], st["phis"], divdt, tdt, psdt)
-    divdt, tdt, psdt = o.implicit_terms(divdt, tdt, psdt)
-    vordt, divdt, tdt, trdt = o.hdiff_step(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], st["tcorh"], st["qcorh"], SDRAG,
-                                           vordt, divdt, tdt, trdt)
-    new, fin = dict(st), {}
-    # (step_field_* truncates its tendency argument in place, time_stepping.f90:146: what the step leaves behind is trunct(fdt))
-    new["ps"], fin["psdt"] = o.step_field(j1, dt, eps, WIL, st["ps"], psdt)
-    for n, d in (("vor", vordt), ("div", divdt), ("t", tdt), ("tr", trdt)):
-        new[n], fin[n + "dt"] = o.step_field(j1, dt, eps, WIL, st[n], d)
-    return new, dict({"U": U, "V": V, "PL": PL, "phi": phi}, **fin)
-
-
-def wave_relerr(x, ref):
-    """max|x - ref| / max|ref| with the global mean -- coefficient (n, m) = (0, 0) of every level -- removed from both:
-    for t the mean is 250*sqrt(2) against waves of O(30/(1+l)), so the plain norm is carried by the mean."""
-    x, ref = np.array(x, copy=True), np.array(ref, copy=True)
-    x[..., 0, 0] = 0.0
-    ref[..., 0, 0] = 0.0
-    return synth.relerr(x, ref)
 
 
 def run_dynamical_core_steps(sp, o, tag, one_launch_tail, nsteps=2, collect=False):

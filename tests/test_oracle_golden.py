@@ -279,10 +279,52 @@ def test_spectral_tendencies_live(oracle_factory):
             close(x, y)
 
 
+@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+def test_dynamics_step_pinned(tag, oracle_factory):
+    """The oracle's whole adiabatic time step (tests/dynstep.py: inverse transforms, grid-space dynamical tendencies, direct
+    transforms, tendency combination, get_spectral_tendencies, implicit_terms, the diffusion block, step_field) against ONE CALL
+    of the reference's own step(j1, j2, dt) -- time_stepping.f90 compiled by flang unchanged, on tendencies.f90 minus its three
+    physics lines (oracle/build_ref.sh) -- and its get_tendencies: golden vectors at 8, 5 and 16 levels, BIT FOR BIT."""
+    from golden.make_golden import DYNSTEP_CASES, DYN63_SUB, STEP_SUB
+    import dynstep
+    z, o = np.load(os.path.join(GOLDEN, "ref_dynstep.npz")), oracle_factory(tag)
+    sub = DYN63_SUB if tag == "t63k16" else STEP_SUB
+    st = dynstep.state(o, 8000)
+    for j1, j2, dt in (DYNSTEP_CASES if tag == "t30" else DYNSTEP_CASES[1:]):
+        o.tail_init(dt)
+        new, out = dynstep.oracle_dynamics_step(o, st, j1, dt, 0.0 if j1 == 1 else dynstep.ROB, j2=j2, before_diffusion=True)
+        key = "%s_j%d%d_" % (tag, j1, j2)
+        for n in ("vor", "div", "t", "tr"):
+            assert np.array_equal(new[n][(Ellipsis,) + sub[1:]], z[key + n]), (key, n)
+        assert np.array_equal(new["ps"], z[key + "ps"]) and np.array_equal(out["phi"][sub], z[key + "phi"]), key
+        for n in ("vordt", "divdt", "tdt", "psdt", "trdt"):             # get_tendencies: before the diffusion and the leapfrog
+            a = out["pre_" + n]
+            assert np.array_equal(a if n == "psdt" else a[sub], z[key + n].reshape((a if n == "psdt" else a[sub]).shape)), (key, n)
+
+
+def test_dynamics_step_live(oracle_factory):
+    """The same against the live flang build: the start-up sequence of first_step and a leapfrog step, chained, full arrays,
+    bit for bit (build container only)."""
+    from oracle.pyoracle import Reference
+    import dynstep
+    if not Reference.available("t30"):
+        pytest.skip("oracle/_ref not built")
+    r, o = Reference("t30"), oracle_factory("t30")
+    if not hasattr(r.lib, "ref_step"):
+        pytest.skip("oracle/_ref predates the adiabatic step build")
+    st_r = st_o = dynstep.state(o, 8100)
+    for j1, j2, dt, eps in ((1, 1, 1200.0, 0.0), (1, 2, 2400.0, 0.0), (2, 2, 4800.0, dynstep.ROB)):
+        r.tail_init(dt); o.tail_init(dt)
+        st_r, phi = r.step(j1, j2, dt, st_r)
+        st_o, out = dynstep.oracle_dynamics_step(o, st_o, j1, dt, eps, j2=j2)
+        for n in ("vor", "div", "t", "tr", "ps"):
+            assert np.array_equal(st_o[n], st_r[n]), (j1, j2, n)
+        assert np.array_equal(out["phi"], phi)
+
+
 def test_step_restatements_selfconsistent(oracle_factory):
-    """The diffusion block of step() cannot be pinned (it is inline in a subroutine that needs NetCDF to compile; step_field and
-    get_spectral_tendencies ARE pinned, tests above): check the restatements against independent NumPy readings of the same
-    source lines, and against the pinned pieces they are built from."""
+    """Independent NumPy readings of the source lines of step_field, get_spectral_tendencies and the diffusion block against the
+    C restatements (kept from the rounds in which those pieces could not be pinned; they are pinned now: tests above)."""
     o = oracle_factory("t30")
     o.tail_init(4800.0)
     kx, nx, mx = o.kx, o.nx, o.mx
