@@ -306,6 +306,51 @@ def run_dynamical_core_steps(sp, o, tag, one_launch_tail, nsteps=2, collect=Fals
     return errs
 
 
+@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+def test_dynamical_core_step_vs_reference_step(tag):
+    """The device step against the REFERENCE'S OWN step(): golden vectors of one call of time_stepping.f90 step(j1, j2, dt) --
+    the file compiled by flang unchanged, on tendencies.f90 minus its three physics lines (tests/golden/ref_dynstep.npz,
+    tests/golden/make_golden.py) -- for the forward half step (j1 = j2 = 1, T30 L8) and the filtered leapfrog step
+    (j1 = j2 = 2) at 8, 5 and 16 levels.  No oracle in between: HIP kernels vs flang-compiled Fortran, 1e-12 of each array's
+    maximum, with and without the global mean."""
+    import os
+    import torch
+    from conftest import ROOT
+    from golden.make_golden import DYNSTEP_CASES, DYN63_SUB, STEP_SUB
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_dynstep.npz"))
+    kx = VARIANTS[tag][3]
+    sp = make_plan(tag, 4 * kx + 4)
+    nx, mx, il, ix = sp.nx, sp.mx, sp.il, sp.ix
+    sub = DYN63_SUB if tag == "t63k16" else STEP_SUB
+    st = state(sp, 8000)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    P = 3 * kx
+    c128 = lambda *shape: torch.zeros(shape, dtype=torch.complex128, device="cuda")
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device="cuda")
+    for j1, j2, dt in (DYNSTEP_CASES if tag == "t30" else DYNSTEP_CASES[1:]):
+        sp.initialize_implicit(dt)
+        D = {n: dev(st[n]) for n in st}
+        ug, vg, plain_g, px, py = f64(kx, il, ix), f64(kx, il, ix), f64(4 * kx, il, ix), f64(1, il, ix), f64(1, il, ix)
+        U, V, PL = f64(P, il, ix), f64(P, il, ix), f64(P + 1, il, ix)
+        pvor, pdiv, pspec, phi = c128(P, nx, mx), c128(P, nx, mx), c128(P + 1, nx, mx), c128(kx, nx, mx)
+        lv = j2 - 1
+        sp.inverse_batch_segs_dev(D["vor"][lv], D["div"][lv], ug, vg, [D[n][lv] for n in ("vor", "div", "t", "tr")], plain_g,
+                                  D["ps"][lv:lv + 1], px, py, kcos_pairs=2, kcos=1)
+        sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
+        sp.direct_batch_spectral_step_dev(U, V, PL, pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"],
+                                          D["tcorh"], D["qcorh"], SDRAG, j1, dt, 0.0 if j1 == 1 else ROB, WIL, phi, kcos=2)
+        sp.synchronize()
+        key = "%s_j%d%d_" % (tag, j1, j2)
+        worst = 0.0
+        for n in ("vor", "div", "t", "tr"):
+            got, ref = D[n].cpu().numpy()[(Ellipsis,) + sub[1:]], z[key + n]
+            worst = max(worst, synth.relerr(got, ref), wave_relerr(got, ref))
+        worst = max(worst, synth.relerr(D["ps"].cpu().numpy(), z[key + "ps"]), wave_relerr(phi.cpu().numpy()[sub], z[key + "phi"]))
+        print("\n[device step vs reference step() %s j1=%d j2=%d dt=%g] worst relative error %.1e" % (tag, j1, j2, dt, worst))
+        assert worst <= TOL, (tag, j1, j2, worst)
+    sp.close()
+
+
 @pytest.mark.parametrize("one_launch_tail", [False, True, "composite"])
 @pytest.mark.parametrize("tag", ["t30", "t63k16", "t30k20"])
 def test_dynamical_core_step_graph(tag, one_launch_tail, oracle_factory):
