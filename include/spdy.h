@@ -66,6 +66,11 @@ enum {
  * inside an open capture is refused with SPDY_ERR_STATE).  Destroying a plan also invalidates the graphs captured
  * from it (spdy_graph_launch then returns SPDY_ERR_STATE) and shuts down its communicators (spdy_comm_*: the handles
  * stay valid for spdy_comm_destroy, every other call on them returns SPDY_ERR_STATE).                              */
+/* Environment read by the library (measurement and debugging aids; none changes results beyond rounding-level path choices):
+ *   SPDY_DEVICE        device index for SPDY_DEVICE_AUTO              SPDY_FUSED = 0 | 1   initial spdy_plan_set_fused mode
+ *   SPDY_WG_PER_CU     persistent workgroups per CU of the T30 kernels (default 1)
+ *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1     SPDY_T63_NOSPLIT     one workgroup per pair in small
+ *                                                                                          T63 direct launches (same bits)  */
 enum { SPDY_MAX_KX = 32, SPDY_DEVICE_NONE = -1, SPDY_DEVICE_AUTO = -2 };
 int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan);
 int spdy_plan_destroy(spdy_plan *plan);
