@@ -74,9 +74,29 @@ build_one() {   # $1 = tag, $2 = sed program for params.f90 ('' = stock), $3 = o
        || [ "$(wc -l < "$REF/tendencies.f90")" -ne "$(( $(wc -l < "$tmp/tendencies.f90") + 3 ))" ]; then
         echo "build_ref: adiabatic tendencies.f90 is not the reference minus its three physics lines"; exit 1
     fi
+    # The gridded snapshot of input_output.f90 (subroutine output, :183-206: uvspec + five inverse transforms per level, then
+    # the float32 conversions with q*1.0e-3, phi/grav, p0*exp(ps)).  The subroutine itself cannot compile here (every other
+    # statement of it is a NetCDF call), so its COMPUTING lines are cut out of the reference file AS THEY ARE, in file order:
+    # the two `use` lines it computes with, its declarations from `vor` to `integer :: k, ncid` (:101-116: the six spectral
+    # arguments, the work arrays, the float32 arrays -- which become dummy arguments of the scratch subroutine simply by being
+    # named in its header line), the transform loop (:183-192) and the conversion block (:199-205).  Written here: the module
+    # frame (the reference module's own `use types` / `use params` / `implicit none` lines) and the subroutine header/end.
+    {   echo "module output_fields_ref"; echo "    use types, only: p, sp"; echo "    use params"; echo "    implicit none"; echo "contains"
+        echo "    subroutine output_fields(vor, div, t, ps, tr, phi, u_out, v_out, t_out, q_out, phi_out, ps_out)"
+        sed -n '/^    subroutine output(/,/^    end subroutine/p' "$REF/input_output.f90" | sed -n \
+            -e '/use physical_constants, only: p0, grav/p' \
+            -e '/use spectral, only: spec_to_grid, uvspec/p' \
+            -e '/complex(p), intent(in) :: vor(mx,nx,kx,2)/,/integer :: k, ncid/p' \
+            -e '/! Convert prognostic fields from spectral space to grid point space/,/ps_grid = spec_to_grid(ps(:,:,1), 1)/p' \
+            -e '/! Preprocess output variables/,/ps_out = real(p0\*exp(ps_grid), sp)/p'
+        echo "    end subroutine"; echo "end module"; } > "$tmp/output_fields_ref.f90"
+    if [ "$(grep -c . "$tmp/output_fields_ref.f90")" -ne 41 ] || ! grep -q "q_out = real(q_grid\*1.0e-3, sp)" "$tmp/output_fields_ref.f90" \
+       || ! grep -q "phi_grid(:,:,k) = spec_to_grid(phi(:,:,k), 1)" "$tmp/output_fields_ref.f90" || grep -q "nf90" "$tmp/output_fields_ref.f90"; then
+        echo "build_ref: output-field extraction of input_output.f90 failed"; exit 1
+    fi
     ( cd "$tmp" && "$FC" $opt -fPIC -shared -w -Wl,-Bsymbolic -o "$OUT/libspeedy_ref_${tag}.so" \
           "${srcs[@]}" "$tmp/step_field_ref.f90" "$tmp/prognostics_decl.f90" "$tmp/spectral_tendencies_ref.f90" \
-          "$tmp/tendencies.f90" "$REF/time_stepping.f90" "$HERE/ref_shim.f90" )
+          "$tmp/tendencies.f90" "$REF/time_stepping.f90" "$tmp/output_fields_ref.f90" "$HERE/ref_shim.f90" )
     rm -rf "$tmp"
     echo "build_ref: built $OUT/libspeedy_ref_${tag}.so"
 }

@@ -393,6 +393,23 @@ class Reference(_Dims):
             threading.stack_size(old)
         return dict(st, **new), phi
 
+    def output(self, vor, div, t, q, phi, ps):
+        """input_output.f90:183-205: the computing lines of the reference's subroutine output, compiled from the reference file
+        (build_ref.sh) -> float32 (u, v, t, q, phi [kx,il,ix], ps [il,ix]).  vor, div, t, q: the time-level-1 slabs.
+        Large-stack thread: the reference keeps its gridded work arrays on the stack (12 MB at T63 L16)."""
+        import threading
+        ins = [_c128(x) for x in (vor, div, t, q, phi, ps)]
+        outs = [np.empty((self.kx,) + self.grid_shape, np.float32) for _ in range(5)] + [np.empty(self.grid_shape, np.float32)]
+
+        def run():
+            self.lib.ref_output_fields(*[_ptr(x) for x in ins], *[_ptr(x) for x in outs])
+        old = threading.stack_size(1 << 30)
+        try:
+            th = threading.Thread(target=run); th.start(); th.join()
+        finally:
+            threading.stack_size(old)
+        return outs
+
     def get_tendencies(self, j2, st):
         """tendencies.f90:11-41 get_tendencies of the same adiabatic build -> (vordt, divdt, tdt, psdt, trdt)."""
         import threading

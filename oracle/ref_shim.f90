@@ -461,3 +461,23 @@ subroutine ref_get_tendencies(j2, i_vor, i_div, i_t, i_tr, i_ps, i_phis, vordt, 
     vordt = (0.0d0, 0.0d0); divdt = (0.0d0, 0.0d0); tdt = (0.0d0, 0.0d0); psdt = (0.0d0, 0.0d0); trdt = (0.0d0, 0.0d0)
     call get_tendencies(vordt, divdt, tdt, psdt, trdt, int(j2))
 end subroutine
+
+! input_output.f90:183-205, the computing lines of subroutine output, compiled from the reference file itself (build_ref.sh
+! cuts them, with the subroutine's own declarations, into the scratch module output_fields_ref).  Inputs: the time-level-1 slabs
+! of vor, div, t, tr(:,:,:,1,1) and ps, and phi; the reference subroutine reads nothing else of its arguments.
+subroutine ref_output_fields(i_vor, i_div, i_t, i_q, i_phi, i_ps, u_out, v_out, t_out, q_out, phi_out, ps_out) bind(C, name="ref_output_fields")
+    use iso_c_binding
+    use params, only: mx, nx, kx, ix, il, ntr
+    use output_fields_ref, only: output_fields
+    complex(c_double_complex), intent(in) :: i_vor(mx,nx,kx), i_div(mx,nx,kx), i_t(mx,nx,kx), i_q(mx,nx,kx), i_phi(mx,nx,kx), i_ps(mx,nx)
+    real(c_float), intent(out) :: u_out(ix,il,kx), v_out(ix,il,kx), t_out(ix,il,kx), q_out(ix,il,kx), phi_out(ix,il,kx), ps_out(ix,il)
+    complex(c_double_complex), allocatable :: vor(:,:,:,:), div(:,:,:,:), t(:,:,:,:), ps(:,:,:), tr(:,:,:,:,:)
+    allocate(vor(mx,nx,kx,2), div(mx,nx,kx,2), t(mx,nx,kx,2), ps(mx,nx,2), tr(mx,nx,kx,2,ntr))
+    vor = (0.0d0, 0.0d0); div = vor; t = vor; ps = (0.0d0, 0.0d0); tr = (0.0d0, 0.0d0)
+    vor(:,:,:,1) = i_vor
+    div(:,:,:,1) = i_div
+    t(:,:,:,1) = i_t
+    tr(:,:,:,1,1) = i_q
+    ps(:,:,1) = i_ps
+    call output_fields(vor, div, t, ps, tr, i_phi, u_out, v_out, t_out, q_out, phi_out, ps_out)
+end subroutine

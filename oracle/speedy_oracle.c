@@ -1086,7 +1086,9 @@ ORC_API void orc_step_field(const orc_ctx *c, int nlev, int j1, double dt, doubl
 }
 
 /* ------------------------------------------------------------------ input_output.f90:184-206: the gridded snapshot
- * PARITY UNPINNED as a sequence (input_output.f90 needs the netcdf module); every transform/operator in it is pinned.
+ * PINNED since the end of round 3: the computing lines of subroutine output (:183-205, with its own declarations) are cut out of
+ * the reference file as they are and compiled by flang (oracle/build_ref.sh: module output_fields_ref); this function equals
+ * them bit for bit in float32 at 8, 5, 7 and 16 levels (tests/golden/ref_output.npz, test_output_fields_pinned/_live).
  * Inputs: time level 1 of vor, div, t, q = tr(:,:,:,1,1), and phi, all (mx,nx,kx); ps (mx,nx).
  * Outputs: float32 arrays u, v, t, q, phi (ix,il,kx) and ps (ix,il).                                              */
 ORC_API void orc_output(const orc_ctx *c, const double *vor, const double *div, const double *t, const double *q,

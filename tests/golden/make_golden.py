@@ -169,6 +169,35 @@ def make_dynstep():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+OUT_SUB = {"t30": (slice(None), slice(None), slice(None, None, 2)), "t30k5": (slice(None), slice(None), slice(None, None, 2)),
+           "t63k16": (slice(None), slice(None, None, 3), slice(None, None, 4))}   # [kx, il, ix] sub-lattices kept per build
+OUT_SEED = 7000
+
+
+def make_output():
+    """ref_output.npz: the gridded snapshot of the flang-built reference -- the computing lines of input_output.f90's subroutine
+    output (:183-205: uvspec, five inverse transforms per level, float32 conversions) cut out of the reference file as they are
+    (oracle/build_ref.sh) -- from the seeded state of tests/dynstep.py at 8, 5 and 16 levels: float32 u, v, t, q, phi
+    (sub-lattices) and ps (whole)."""
+    import dynstep
+    from oracle.pyoracle import Oracle
+    d = {}
+    for tag, sub in OUT_SUB.items():
+        r = Reference(tag)
+        o = Oracle(r.trunc, r.ix, r.iy, r.kx)
+        if tag == "t63k16":
+            o.set_sigma(synth.SIGMA_L16)
+            r.set_sigma(*[o.table(n) for n in ("hsg", "dhs", "fsg", "dhsr", "fsgr")])
+        st = dynstep.state(o, OUT_SEED)
+        phi = r.geopotential(st["t"][0], st["phis"])
+        outs = r.output(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], phi, st["ps"][0])
+        for n, a in zip(("u", "v", "t", "q", "phi", "ps"), outs):
+            d["%s_%s" % (tag, n)] = a if n == "ps" else a[sub]
+    out = os.path.join(HERE, "ref_output.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
 def make(tag, nb_grid, dts, imp_dts, lean):
     r = Reference(tag)
     tr, ix, il, kx, nx, mx = r.trunc, r.ix, r.il, r.kx, r.nx, r.mx
@@ -237,6 +266,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dynstep":   # only the adiabatic-step fixture
         make_dynstep()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "output":    # only the gridded-snapshot fixture
+        make_output()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "spectend":  # only the get_spectral_tendencies fixture
         make_spectend()
         sys.exit(0)
@@ -246,3 +278,4 @@ if __name__ == "__main__":
     make_step()
     make_spectend()
     make_dynstep()
+    make_output()

@@ -8,6 +8,8 @@ Since the end of round 3 the WHOLE adiabatic step of the oracle (tests/dynstep.p
 get_spectral_tendencies, the diffusion block of step() included) is pinned bit for bit to the reference's own
 time_stepping.f90 / tendencies.f90 compiled by flang (oracle/build_ref.sh: tendencies.f90 minus its three physics lines;
 tests/test_oracle_golden.py::test_dynamics_step_pinned)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,6 +198,38 @@ def test_model_step_graph(tag, oracle_factory):
         for n in ("ps", "vor", "div", "t", "tr"):
             ok(D[n].cpu().numpy(), ref[n])
     g.close()
+    sp.close()
+
+
+@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+def test_output_path_vs_reference(tag, oracle_factory):
+    """SURVEY s8 f4 against the REFERENCE, no oracle in between: spdy_output_batch_dev on the seeded state vs the golden float32
+    fields of the reference's own lines (input_output.f90:183-205 cut out of the file as they are and compiled by flang,
+    tests/golden/ref_output.npz) at 8, 5 and 16 levels.  Every value within one float32 ulp; the five linear fields differ in
+    at most a handful of values (an FP64 difference of 1e-15 only shows next to a float32 rounding boundary)."""
+    import torch
+    from golden.make_golden import OUT_SUB, OUT_SEED
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_output.npz"))
+    sp, o = make_plan(tag, 4 * VARIANTS[tag][3] + 4), oracle_factory(tag)
+    kx, il, ix = sp.kx, sp.il, sp.ix
+    st = state(sp, OUT_SEED)
+    phi = o.geopotential(st["t"][0], st["phis"])            # an INPUT of the snapshot (pinned: test_other_level_counts_and_geopotential)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ins = [dev(st[n][0]) for n in ("vor", "div", "t", "tr")] + [dev(phi), dev(st["ps"][0])]
+    outs = [torch.zeros((kx, il, ix), dtype=torch.float32, device="cuda") for _ in range(5)] + [torch.zeros((il, ix), dtype=torch.float32, device="cuda")]
+    sp.output_batch_dev(*ins, *outs)
+    torch.cuda.synchronize()
+    flips = total = 0
+    for name, a in zip(("u", "v", "t", "q", "phi", "ps"), outs):
+        a = a.cpu().numpy()
+        a = a if name == "ps" else a[OUT_SUB[tag]]
+        b = z["%s_%s" % (tag, name)]
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, (name, ulp.max())
+        if name != "ps":
+            flips += int((ulp != 0).sum()); total += b.size
+    print("output path vs reference %s: %d of %d linear float32 values differ by one ulp" % (tag, flips, total))
+    assert flips <= 8, flips
     sp.close()
 
 

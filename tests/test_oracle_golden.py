@@ -322,6 +322,41 @@ def test_dynamics_step_live(oracle_factory):
         assert np.array_equal(out["phi"], phi)
 
 
+@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+def test_output_fields_pinned(tag, oracle_factory):
+    """The gridded snapshot (input_output.f90:183-205: uvspec + five inverse transforms per level, float32 conversions with
+    q*1.0e-3, phi/grav, p0*exp(ps)): the C oracle against the reference's own lines, cut out of input_output.f90 as they are and
+    compiled by flang (oracle/build_ref.sh) -- golden vectors at 8, 5 and 16 levels.  BIT FOR BIT in float32 for the five linear
+    fields; ps_out goes through libm's exp() and is held to one float32 ulp (it is bit-equal on the build image)."""
+    from golden.make_golden import OUT_SUB, OUT_SEED
+    import dynstep
+    z, o = np.load(os.path.join(GOLDEN, "ref_output.npz")), oracle_factory(tag)
+    st = dynstep.state(o, OUT_SEED)
+    phi = o.geopotential(st["t"][0], st["phis"])
+    outs = o.output(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], phi, st["ps"][0])
+    for n, a in zip(("u", "v", "t", "q", "phi"), outs):
+        assert np.array_equal(a[OUT_SUB[tag]].view(np.int32), z["%s_%s" % (tag, n)].view(np.int32)), (tag, n)
+    ulp = np.abs(outs[5].view(np.int32).astype(np.int64) - z[tag + "_ps"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, ulp.max()
+
+
+def test_output_fields_live(oracle_factory):
+    """The same against the live flang build at T30 L8 and T63 L8 on another seed, whole arrays (build container only)."""
+    from oracle.pyoracle import Reference
+    import dynstep
+    for tag in ("t30", "t63"):
+        if not Reference.available(tag):
+            pytest.skip("oracle/_ref not built")
+        r, o = Reference(tag), oracle_factory(tag)
+        if not hasattr(r.lib, "ref_output_fields"):
+            pytest.skip("oracle/_ref predates the output-field extraction")
+        st = dynstep.state(o, 7100)
+        phi = o.geopotential(st["t"][0], st["phis"])
+        args = (st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], phi, st["ps"][0])
+        for n, a, b in zip(("u", "v", "t", "q", "phi", "ps"), o.output(*args), r.output(*args)):
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), (tag, n)
+
+
 def test_step_restatements_selfconsistent(oracle_factory):
     """Independent NumPy readings of the source lines of step_field, get_spectral_tendencies and the diffusion block against the
     C restatements (kept from the rounds in which those pieces could not be pinned; they are pinned now: tests above)."""
