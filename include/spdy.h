@@ -59,7 +59,8 @@ enum {
  * device = SPDY_DEVICE_NONE builds a host-only plan (tables only: lets CPU-side tests inspect tables; every compute
  * call on it returns SPDY_ERR_NO_DEVICE).
  * max_batch bounds nb of every batched call.  Device memory beyond the tables (< 10 MB) is allocated on demand:
- * the host-pointer entry points stage through 4 x max_batch grids from their first call on; the four-kernel path
+ * the host-pointer entry points stage through 4 x max_batch grids (+ 4 x 512 KB of pinned host memory for small calls,
+ * $SPDY_HOST_STAGE_KB below) from their first call on; the four-kernel path
  * (spdy_plan_set_fused(0)) and the T63 operator+transform sequences
  * keep a workspace of max_batch x (il x 2mx + 2 mx nx complex) doubles, allocated at plan creation when it is <= 64 MB
  * (model-shaped plans: a graph capture then needs no warm-up) and at the first call that needs it otherwise (allocation
@@ -70,7 +71,11 @@ enum {
  *   SPDY_DEVICE        device index for SPDY_DEVICE_AUTO              SPDY_FUSED = 0 | 1   initial spdy_plan_set_fused mode
  *   SPDY_WG_PER_CU     persistent workgroups per CU of the T30 kernels (default 1)
  *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1     SPDY_T63_NOSPLIT     one workgroup per pair in small
- *                                                                                          T63 direct launches (same bits)  */
+ *                                                                                          T63 direct launches (same bits)
+ *   SPDY_HOST_STAGE_KB host-pointer calls whose largest array is at most this many KB (default 512; 0 = never) stage through
+ *                      pinned host memory mapped into the device: the caller's thread copies in and out, the kernels read and
+ *                      write the staging buffers across the link themselves (no copy-engine round trips: 1.4-1.6x the rate
+ *                      of one-field calls); larger calls use device staging and hipMemcpyAsync.  Same bits either way.      */
 enum { SPDY_MAX_KX = 32, SPDY_DEVICE_NONE = -1, SPDY_DEVICE_AUTO = -2 };
 int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int device, spdy_plan **plan);
 int spdy_plan_destroy(spdy_plan *plan);

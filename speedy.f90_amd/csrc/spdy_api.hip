@@ -3,6 +3,7 @@
 // without a device can only report its tables.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -316,18 +317,37 @@ int ensure_four(spdy_plan *p)
     return SPDY_OK;
 }
 
-int ensure_staging(spdy_plan *p)
+int ensure_staging(spdy_plan *p, size_t elems)
 {
-    if (p->stage_a) return SPDY_OK;
     NOT_CAPTURING(p, "a host-pointer entry point");
-    // four buffers big enough for max_batch grids (the largest array kind)
-    p->stage_elems = (size_t)p->max_batch * p->tab.il * p->tab.ix;
-    double **stages[4] = {&p->stage_a, &p->stage_b, &p->stage_c, &p->stage_d};
-    void *ptr;
-    for (auto s : stages) {
-        RC(dev_alloc(p, p->stage_elems * sizeof(double), &ptr));
-        *s = static_cast<double *>(ptr);
+    if (!p->dstage[0]) {
+        // four buffers big enough for max_batch grids (the largest array kind)
+        p->stage_elems = (size_t)p->max_batch * p->tab.il * p->tab.ix;
+        void *ptr;
+        for (int i = 0; i < 4; ++i) {
+            RC(dev_alloc(p, p->stage_elems * sizeof(double), &ptr));
+            p->dstage[i] = static_cast<double *>(ptr);
+        }
+        // the host-mapped twin set for small calls (spdy_plan::hstage); any failure here just leaves the route off
+        size_t kb = 512;
+        if (const char *env = getenv("SPDY_HOST_STAGE_KB")) kb = (size_t)(atol(env) > 0 ? atol(env) : 0);
+        const size_t want = std::min(p->stage_elems, kb * 1024 / sizeof(double));
+        if (want >= grid_elems(p)) {
+            bool ok = true;
+            for (int i = 0; i < 4 && ok; ++i) {
+                ok = hipHostMalloc(&ptr, want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+                if (ok) p->hstage[i] = static_cast<double *>(ptr);
+            }
+            if (ok) ok = hipHostMalloc(&ptr, sizeof(int) * (size_t)p->max_batch, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+            if (ok) { p->h_kcos = static_cast<int *>(ptr); p->hstage_elems = want; }
+            else {
+                (void)hipGetLastError();
+                for (int i = 0; i < 4; ++i) { if (p->hstage[i]) (void)hipHostFree(p->hstage[i]); p->hstage[i] = nullptr; }
+            }
+        }
     }
+    double *const *set = (p->hstage_elems && elems <= p->hstage_elems) ? p->hstage : p->dstage;
+    p->stage_a = set[0]; p->stage_b = set[1]; p->stage_c = set[2]; p->stage_d = set[3];
     return SPDY_OK;
 }
 
@@ -337,22 +357,38 @@ int check_batch(const spdy_plan *p, int nb)
     return SPDY_OK;
 }
 
+static bool in_host_stage(const spdy_plan *p, const double *ptr)
+{
+    for (int i = 0; i < 4; ++i)
+        if (p->hstage[i] && ptr >= p->hstage[i] && ptr < p->hstage[i] + p->hstage_elems) return true;
+    return false;
+}
+
 int h2d(spdy_plan *p, double *dst, const double *src, size_t n)
 {
     NOT_CAPTURING(p, "a host-pointer entry point");
-    if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if (!n) return SPDY_OK;
+    // host-mapped staging: nothing is in flight on it (every host-pointer call ends with sync), the kernels read it in place
+    if (in_host_stage(p, dst)) std::memcpy(dst, src, n * sizeof(double));
+    else HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, p->stream));
     return SPDY_OK;
 }
 int d2h(spdy_plan *p, double *dst, const double *src, size_t n)
 {
     NOT_CAPTURING(p, "a host-pointer entry point");
-    if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (!n) return SPDY_OK;
+    if (in_host_stage(p, src)) p->pending.push_back({dst, src, n * sizeof(double)});   // copied out by sync()
+    else HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     return SPDY_OK;
 }
 int sync(spdy_plan *p)
 {
     NOT_CAPTURING(p, "synchronising");
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    const hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) p->pending.clear();
+    HIP_TRY(e);
+    for (const auto &c : p->pending) std::memcpy(c.dst, c.src, c.bytes);
+    p->pending.clear();
     return SPDY_OK;
 }
 
@@ -518,6 +554,8 @@ int spdy_plan_destroy(spdy_plan *p)
         // valid for spdy_comm_destroy; every other call on them returns SPDY_ERR_STATE)
         release_comms(p);
         for (void *a : p->allocs) (void)hipFree(a);
+        for (double *h : p->hstage) if (h) (void)hipHostFree(h);
+        if (p->h_kcos) (void)hipHostFree(p->h_kcos);
         if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     }
     delete p;
@@ -681,11 +719,18 @@ int spdy_spec_to_grid_batch(spdy_plan *p, int nb, const double *spec, const int 
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
-    RC(ensure_staging(p));
+    RC(ensure_staging(p, nb * grid_elems(p)));
     if (nb && (!spec || !grid)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, spec, nb * spec_elems(p)));
-    if (kcos && nb) HIP_TRY(hipMemcpyAsync(p->d_kcos, kcos, sizeof(int) * nb, hipMemcpyHostToDevice, p->stream));
-    RC(spdy_spec_to_grid_dev(p, nb, p->stage_a, kcos ? p->d_kcos : nullptr, 1, p->stage_b));
+    // one flag for the whole batch (always so for the reference's one-field calls): passed by value, no array to move
+    bool same = true;
+    for (int i = 1; kcos && i < nb; ++i) same = same && kcos[i] == kcos[0];
+    const int *dk = nullptr;
+    if (kcos && nb && !same) {
+        if (on_host_stage(p)) { std::memcpy(p->h_kcos, kcos, sizeof(int) * nb); dk = p->h_kcos; }
+        else { HIP_TRY(hipMemcpyAsync(p->d_kcos, kcos, sizeof(int) * nb, hipMemcpyHostToDevice, p->stream)); dk = p->d_kcos; }
+    }
+    RC(spdy_spec_to_grid_dev(p, nb, p->stage_a, dk, (kcos && nb) ? kcos[0] : 1, p->stage_b));
     RC(d2h(p, grid, p->stage_b, nb * grid_elems(p)));
     return sync(p);
 }
@@ -694,7 +739,7 @@ int spdy_grid_to_spec_batch(spdy_plan *p, int nb, const double *grid, double *sp
 {
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
-    RC(ensure_staging(p));
+    RC(ensure_staging(p, nb * grid_elems(p)));
     if (nb && (!spec || !grid)) return fail(SPDY_ERR_ARG, "null pointer");
     RC(h2d(p, p->stage_a, grid, nb * grid_elems(p)));
     RC(spdy_grid_to_spec_dev(p, nb, p->stage_a, p->stage_b));
@@ -848,7 +893,7 @@ static int derived_to_grid_host(spdy_plan *p, int nb, int mode, const double *in
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!in0 || (mode == 1 && !in1) || !g0 || !g1)) return fail(SPDY_ERR_ARG, "null pointer");
-    RC(ensure_staging(p));
+    RC(ensure_staging(p, nb * grid_elems(p)));
     RC(h2d(p, p->stage_a, in0, nb * spec_elems(p)));
     if (mode == 1) RC(h2d(p, p->stage_b, in1, nb * spec_elems(p)));
     RC(derived_to_grid(p, nb, mode, p->stage_a, p->stage_b, p->stage_c, p->stage_d, kcos));
@@ -1066,7 +1111,7 @@ int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const doub
         NEED_DEVICE(p);                                                            \
         RC(check_batch(p, nb));                                                    \
         if (nb && (!in || !out)) return fail(SPDY_ERR_ARG, "null pointer");        \
-        RC(ensure_staging(p));                                                     \
+        RC(ensure_staging(p, nb * spec_elems(p)));                                 \
         RC(h2d(p, p->stage_a, in, nb * spec_elems(p)));                            \
         RC(devfn(p, nb, p->stage_a, p->stage_b));                                  \
         RC(d2h(p, out, p->stage_b, nb * spec_elems(p)));                           \
@@ -1080,7 +1125,7 @@ int spdy_trunct(spdy_plan *p, int nb, double *inout)
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && !inout) return fail(SPDY_ERR_ARG, "null pointer");
-    RC(ensure_staging(p));
+    RC(ensure_staging(p, nb * spec_elems(p)));
     RC(h2d(p, p->stage_a, inout, nb * spec_elems(p)));
     RC(spdy_trunct_dev(p, nb, p->stage_a));
     RC(d2h(p, inout, p->stage_a, nb * spec_elems(p)));
@@ -1092,7 +1137,7 @@ int spdy_grad(spdy_plan *p, int nb, const double *psi, double *psdx, double *psd
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!psi || !psdx || !psdy)) return fail(SPDY_ERR_ARG, "null pointer");
-    RC(ensure_staging(p));
+    RC(ensure_staging(p, nb * spec_elems(p)));
     const size_t n = nb * spec_elems(p);
     RC(h2d(p, p->stage_a, psi, n));
     // rows of psdy the reference leaves untouched keep the caller's values
@@ -1109,7 +1154,7 @@ int spdy_grad(spdy_plan *p, int nb, const double *psi, double *psdx, double *psd
         NEED_DEVICE(p);                                                                              \
         RC(check_batch(p, nb));                                                                      \
         if (nb && (!a || !b || !c || !d)) return fail(SPDY_ERR_ARG, "null pointer");                 \
-        RC(ensure_staging(p));                                                                       \
+        RC(ensure_staging(p, nb * spec_elems(p)));                                                   \
         const size_t n = nb * spec_elems(p);                                                         \
         RC(h2d(p, p->stage_a, a, n));                                                                \
         RC(h2d(p, p->stage_b, b, n));                                                                \
@@ -1128,7 +1173,7 @@ int spdy_vdspec(spdy_plan *p, int nb, const double *ug, const double *vg, double
     NEED_DEVICE(p);
     RC(check_batch(p, nb));
     if (nb && (!ug || !vg || !vorm || !divm)) return fail(SPDY_ERR_ARG, "null pointer");
-    RC(ensure_staging(p));
+    RC(ensure_staging(p, nb * grid_elems(p)));
     RC(h2d(p, p->stage_a, ug, nb * grid_elems(p)));
     RC(h2d(p, p->stage_b, vg, nb * grid_elems(p)));
     // (the one-pass kernel writes vorticity/divergence while other workgroups still read grids: outputs never alias inputs)

@@ -25,8 +25,19 @@ struct spdy_plan {
     std::vector<void *> allocs;       // everything hipMalloc'ed for this plan
     double *four = nullptr;           // [max_batch][il][fs] Fourier workspace (four-kernel path only; allocated on demand)
     // host-pointer API staging: four buffers of max_batch grids each, allocated at the first host-pointer call
-    double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;
+    double *stage_a = nullptr, *stage_b = nullptr, *stage_c = nullptr, *stage_d = nullptr;   // the set the current call uses
     size_t stage_elems = 0;
+    // Small host-pointer calls (the reference's one-field-per-call pattern, level stacks) skip both PCIe copy engines: their
+    // staging buffers are PINNED HOST memory mapped into the device's address space -- the input is memcpy'ed into it by the
+    // calling thread, the kernels read and write it across the link themselves, and the result is memcpy'ed out after the
+    // stream synchronisation that ends every host-pointer call (`pending`).  $SPDY_HOST_STAGE_KB (default 512; 0 = off) is
+    // the largest per-buffer size that takes this route; larger calls use the device set and hipMemcpyAsync as before.
+    double *dstage[4] = {nullptr, nullptr, nullptr, nullptr};   // device memory, max_batch grids each
+    double *hstage[4] = {nullptr, nullptr, nullptr, nullptr};   // hipHostMalloc (mapped, coherent), hstage_elems doubles each
+    int *h_kcos = nullptr;                                      // hstage-route twin of d_kcos
+    size_t hstage_elems = 0;
+    struct Pending { void *dst; const void *src; size_t bytes; };
+    std::vector<Pending> pending;     // device-written host-stage results still to be copied to the caller's arrays
     const double *d_zero_spec = nullptr;         // one all-zero spectrum (gradient tiles of the mixed inverse kernel)
     double *tmp_c = nullptr, *tmp_d = nullptr;   // max_batch spectra each; allocated with `four` (multi-kernel operator sequences)
     double *out_grid = nullptr, *out_spec = nullptr;   // output path: (5kx+1) grids, (3kx+1) spectra (spdy_output_workspace)
@@ -56,7 +67,10 @@ int check_batch(const spdy_plan *p, int nb);
 int h2d(spdy_plan *p, double *dst, const double *src, size_t n);
 int d2h(spdy_plan *p, double *dst, const double *src, size_t n);
 int sync(spdy_plan *p);
-int ensure_staging(spdy_plan *p);     // host-pointer entry points call this first
+// host-pointer entry points call this first; elems = the largest array (in doubles) the call puts into ONE staging buffer:
+// selects the host-mapped set when it fits (see spdy_plan::hstage), the device set otherwise / by default
+int ensure_staging(spdy_plan *p, size_t elems = (size_t)-1);
+inline bool on_host_stage(const spdy_plan *p) { return p->hstage[0] && p->stage_a == p->hstage[0]; }
 int ensure_four(spdy_plan *p);        // four-kernel path workspace
 // T63 fused path: the direct batch WITHOUT vds -- the scaled (u, v) grids' spectra go to p->tmp_c / p->tmp_d, the plain
 // grids' to spec (spdy_direct_batch_spectral_step_dev)

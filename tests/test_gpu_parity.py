@@ -289,3 +289,29 @@ def test_kcos_other_values_mean_cosgr(plans, golden):
         ug, vg = sp.uvspec_to_grid(S[0], S[1], kc)
         ug2, vg2 = sp.uvspec_to_grid(S[0], S[1], 2)
         assert np.array_equal(ug, ug2) and np.array_equal(vg, vg2)
+
+
+@pytest.mark.parametrize("tag", ["t30", "t63"])
+def test_host_staging_routes_agree(tag, monkeypatch):
+    """Host-pointer calls: the pinned host-mapped staging route of small calls (the kernels read and write the staging buffers
+    across the link themselves, spdy_plan::hstage) and the device-staging route (hipMemcpyAsync both ways, SPDY_HOST_STAGE_KB=0)
+    give the same bits -- transforms with one flag and with per-field kcos, the two-array operators, in-place trunct -- and a
+    batch larger than the threshold falls back to the device route inside the same plan."""
+    import speedy_f90_amd as s
+    res = {}
+    for kb in ("0", "512"):
+        monkeypatch.setenv("SPDY_HOST_STAGE_KB", kb)          # read when the plan allocates its staging (first host-pointer call)
+        sp = s.Spectral(tag, kx=8, max_batch=64, device=0)
+        S = synth.spectra(64, sp.trunc, first=4100, full_rows=True)
+        G = synth.grids(64, sp.ix, sp.il, first=4100)
+        out = []
+        for nb in (1, 3, 64):                                  # 64 grids: 2.4 MB (T30) / 9.4 MB (T63) per buffer -> device route
+            kc = np.array([1 + (b % 3 == 1) for b in range(nb)], np.int32)
+            out += [sp.spec_to_grid(S[:nb], 2), sp.spec_to_grid(S[:nb], kc), sp.grid_to_spec(G[:nb])]
+            out += list(sp.uvspec(S[:nb], S[nb - 1::-1])) + list(sp.vdspec(G[:nb], G[nb - 1::-1], 2)) + [sp.trunct(S[:nb])]
+        out += [sp.spec_to_grid(S[5], 1), sp.grid_to_spec(G[5])]
+        res[kb] = out
+        sp.close()
+    assert len(res["0"]) == len(res["512"])
+    for a, b in zip(res["0"], res["512"]):
+        assert a.shape == b.shape and np.array_equal(a, b)
