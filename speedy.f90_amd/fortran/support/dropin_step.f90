@@ -2,7 +2,7 @@
 !  the model's own start-up sequence (first_step) and `nleap` leapfrog steps exactly as the model's main loop would
 !  (speedy.f90: call step(2, 2, 2*delt)), and writes the state after every step for the test to compare with the reference sequence.
 program dropin_step
-    use types, only: p
+    use types, only: p, sp
     use params
     use spectral, only: initialize_spectral, finalize_spectral
     use horizontal_diffusion, only: initialize_horizontal_diffusion, tcorh, qcorh
@@ -11,6 +11,8 @@ program dropin_step
     use time_stepping
     implicit none
     complex(p) :: vordt(mx,nx,kx), divdt(mx,nx,kx), tdt(mx,nx,kx), psdt(mx,nx), trdt(mx,nx,kx,ntr)
+    real(sp), dimension(ix,il,kx) :: u_out, v_out, t_out, q_out, phi_out
+    real(sp) :: ps_out(ix,il)
     integer :: nleap, i
     integer(8) :: c0, c1, cr
     logical :: return_now = .false.
@@ -55,6 +57,12 @@ program dropin_step
     open(11, file=trim(fout), access='stream', form='unformatted', status='replace')
     call first_step                      ! forward half step, first leapfrog step (both written below as one record)
     call dump
+    ! the gridded snapshot (input_output.f90:183-205) after the start-up sequence, straight from the device-resident prognostics
+    ! (the seeded test state is not a balanced one: a few 40-minute leapfrog steps later it no longer fits float32)
+    call output_fields_from_device(u_out, v_out, t_out, q_out, phi_out, ps_out)
+    open(12, file=trim(fout)//'.snapshot', access='stream', form='unformatted', status='replace')
+    write(12) u_out, v_out, t_out, q_out, phi_out, ps_out
+    close(12)
     do i = 1, nleap
         call step(2, 2, 2*delt)
         call dump

@@ -3,9 +3,9 @@
 !  these two modules are the model's own (source/types.f90, source/params.f90) and this file is
 !  not compiled.  Resolution is chosen with -DSPDY_T63 (default T30), like editing params.f90.
 module types
-    use iso_fortran_env, only: real64
+    use iso_fortran_env, only: real32, real64
     implicit none
-    integer, parameter :: p = real64
+    integer, parameter :: sp = real32, dp = real64, p = dp      ! types.f90:10-12
 end module
 
 module params

@@ -26,7 +26,7 @@
 !  prognostics_to_device.
 module time_stepping
     use iso_c_binding
-    use types, only: p
+    use types, only: p, sp
     use params
     use spdy_c
     use spectral, only: spectral_plan, initialize_spectral
@@ -37,6 +37,7 @@ module time_stepping
     public first_step, step
     ! extensions (not in the reference)
     public prognostics_to_device, prognostics_from_device, tendencies_from_device, finalize_time_stepping
+    public output_fields_from_device
 
     integer(c_size_t), parameter :: spec_bytes = 16_c_size_t*mx*nx, grid_bytes = 8_c_size_t*ix*il
 
@@ -49,6 +50,7 @@ module time_stepping
     type(c_ptr) :: d_ug = c_null_ptr, d_vg = c_null_ptr, d_plain = c_null_ptr, d_px = c_null_ptr, d_py = c_null_ptr
     type(c_ptr) :: d_u = c_null_ptr, d_v = c_null_ptr, d_pl = c_null_ptr
     type(c_ptr) :: d_pvor = c_null_ptr, d_pdiv = c_null_ptr, d_pspec = c_null_ptr
+    type(c_ptr) :: d_out = c_null_ptr                 ! float32 snapshot fields: u, v, t, q, phi (ix,il,kx) | ps (ix,il)
     ! the captured leapfrog step and what it was captured for
     type(c_ptr) :: graph = c_null_ptr
     integer :: graph_j1 = 0, graph_j2 = 0
@@ -237,6 +239,32 @@ contains
         call spdy_check(spdy_dev_download(spectral_plan, psdt, at(d_pspec, 3*kx*spec_bytes), spec_bytes), 'download psdt')
     end subroutine
 
+    !> The gridded snapshot of input_output.f90:183-205 from the DEVICE-resident state: what the reference's subroutine output
+    !  computes between its NetCDF calls -- uvspec + five spec_to_grid per level on time level 1 of vor, div, t, tr and on phi,
+    !  spec_to_grid of ps, then real(., sp) of u, v, t, q*1.0e-3, phi/grav, p0*exp(ps) -- as ONE transform launch of 5 kx + 1
+    !  fields and a float32 epilogue (spdy_output_batch_dev); only the six float32 arrays cross the link.  A host keeps its
+    !  NetCDF writer and replaces the two computing blocks of `output` by this call (INTEGRATION.md).
+    subroutine output_fields_from_device(u_out, v_out, t_out, q_out, phi_out, ps_out)
+        real(sp), dimension(ix,il,kx), intent(out) :: u_out, v_out, t_out, q_out, phi_out
+        real(sp), intent(out) :: ps_out(ix,il)
+        integer(c_size_t), parameter :: fb = 4_c_size_t*ix*il
+
+        if (.not. resident) error stop 'time_stepping%output_fields_from_device before the first step'
+        if (.not. c_associated(d_out)) then
+            call alloc(d_out, (5*kx + 1)*fb)
+            call spdy_check(spdy_output_workspace(spectral_plan), 'output_workspace')
+        end if
+        ! time level 1 is the leading (mx,nx,kx) slab of every prognostic array
+        call spdy_check(spdy_output_batch_dev(spectral_plan, d_vor, d_div, d_t, d_tr, d_phi, d_ps, &
+            & d_out, at(d_out, kx*fb), at(d_out, 2*kx*fb), at(d_out, 3*kx*fb), at(d_out, 4*kx*fb), at(d_out, 5*kx*fb)), 'output_batch')
+        call spdy_check(spdy_dev_download(spectral_plan, u_out, d_out, kx*fb), 'download u_out')
+        call spdy_check(spdy_dev_download(spectral_plan, v_out, at(d_out, kx*fb), kx*fb), 'download v_out')
+        call spdy_check(spdy_dev_download(spectral_plan, t_out, at(d_out, 2*kx*fb), kx*fb), 'download t_out')
+        call spdy_check(spdy_dev_download(spectral_plan, q_out, at(d_out, 3*kx*fb), kx*fb), 'download q_out')
+        call spdy_check(spdy_dev_download(spectral_plan, phi_out, at(d_out, 4*kx*fb), kx*fb), 'download phi_out')
+        call spdy_check(spdy_dev_download(spectral_plan, ps_out, at(d_out, 5*kx*fb), fb), 'download ps_out')
+    end subroutine
+
     !> Releases the captured step and the device state (before spectral%finalize_spectral).
     subroutine finalize_time_stepping
         if (c_associated(graph)) call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
@@ -245,6 +273,7 @@ contains
         call release(d_phis); call release(d_tcorh); call release(d_qcorh)
         call release(d_ug); call release(d_vg); call release(d_plain); call release(d_px); call release(d_py)
         call release(d_u); call release(d_v); call release(d_pl); call release(d_pvor); call release(d_pdiv); call release(d_pspec)
+        call release(d_out)
         resident = .false.
     end subroutine
 

@@ -208,6 +208,7 @@ def test_time_stepping_dropin_vs_oracle(tag, phys, tmp_path, oracle_factory):
     o.tail_init(delt); ref, out = oracle_dynamics_step(o, ref, 1, delt, 0.0, j2=2, physics=hook)
     o.tail_init(2 * delt)
     worst = {}
+    snap_want = o.output(ref["vor"][0], ref["div"][0], ref["t"][0], ref["tr"][0], out["phi"], ref["ps"][0])   # snapshot after first_step
     for rec in range(1 + nleap):
         if rec:
             ref, out = oracle_dynamics_step(o, ref, 2, 2 * delt, ROB, j2=2, physics=hook)
@@ -222,4 +223,22 @@ def test_time_stepping_dropin_vs_oracle(tag, phys, tmp_path, oracle_factory):
             worst[n] = max(worst.get(n, 0.0), e)
             assert e <= TOL, (tag, rec, n, e)
     assert pos[0] == raw.size
+    # the gridded snapshot after the start-up sequence, from the device-resident prognostics (output_fields_from_device = the computing
+    # lines of input_output.f90:183-205; the oracle's restatement of them is pinned bit for bit: test_output_fields_pinned).
+    # the device state differs from the oracle's by ~1e-14, so a value next to a float32 rounding boundary may land on the
+    # other side: at most one value in 2000 may differ at all, and by no more than half a float32 ulp of the array's maximum
+    snap = np.fromfile(str(fout) + ".snapshot", np.float32)
+    il, ix = o.il, o.ix
+    assert all(np.isfinite(b).all() for b in snap_want)
+    assert snap.size == (5 * kx + 1) * il * ix
+    flips = 0
+    for i, (n, b) in enumerate(zip(("u", "v", "t", "q", "phi", "ps"), snap_want)):
+        a = snap[i * kx * il * ix:][:b.size].reshape(b.shape)
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        # (a value near zero moves by many of ITS ulps when the state moves by 1e-14 of the maximum: the bound is half a
+        # float32 ulp of the array's maximum, and values that differ at all are counted)
+        assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 6e-8 * np.abs(b).max(), (tag, n, int(ulp.max()))
+        flips += int((ulp != 0).sum())
+    assert flips <= snap.size // 2000, flips
+    worst["snapshot_flips"] = float(flips)
     print("\n[time_stepping drop-in %s%s] worst relative errors: " % (tag, " + host physics" if phys else "") + " ".join("%s %.1e" % kv for kv in worst.items()))
