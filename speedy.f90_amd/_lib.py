@@ -23,6 +23,7 @@ SIGNATURES = {
     "spdy_dev_upload": [c_void_p, c_void_p, c_void_p, ctypes.c_size_t],
     "spdy_dev_download": [c_void_p, c_void_p, c_void_p, ctypes.c_size_t],
     "spdy_plan_dims": [c_void_p, ctypes.POINTER(c_int)],
+    "spdy_wave_placement": [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "spdy_plan_set_profiling": [c_void_p, c_int],
     "spdy_plan_set_fused": [c_void_p, c_int],
     "spdy_plan_get_profile": [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int)],

@@ -655,6 +655,34 @@ int spdy_plan_get_profile(spdy_plan *p, double *ms, int *launches)
     return SPDY_OK;
 }
 
+int spdy_wave_placement(spdy_plan *p, int *simd_of_wave, int *violations)
+{
+    NEED_DEVICE(p);
+    NOT_CAPTURING(p, "spdy_wave_placement");
+    if (!simd_of_wave || !violations) return fail(SPDY_ERR_ARG, "null output");
+    const int nwg = p->num_cu;
+    void *ptr = nullptr;
+    HIP_TRY(hipMalloc(&ptr, sizeof(int) * 8 * (size_t)nwg));
+    std::vector<int> h(8 * (size_t)nwg, -1);
+    hipError_t e = spdy::launch_wave_placement(static_cast<int *>(ptr), nwg, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), ptr, sizeof(int) * h.size(), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(ptr);
+    HIP_TRY(e);
+    int bad = 0;
+    for (int g = 0; g < nwg; ++g) {
+        const int *w = &h[8 * (size_t)g];
+        bool ok = true;
+        for (int i = 0; i < 4; ++i) ok = ok && w[i] == w[i + 4] && w[i] >= 0 && w[i] < 4;
+        for (int i = 0; i < 4 && ok; ++i)
+            for (int j = i + 1; j < 4; ++j) ok = ok && w[i] != w[j];
+        bad += ok ? 0 : 1;
+    }
+    std::memcpy(simd_of_wave, h.data(), sizeof(int) * 8);
+    *violations = bad;
+    return SPDY_OK;
+}
+
 int spdy_plan_dims(const spdy_plan *p, int *dims)
 {
     NEED_PLAN(p);

@@ -1027,4 +1027,29 @@ hipError_t launch_hdiff(const DevPlan &p, int nlev, const double *field, const d
     return hipGetLastError();
 }
 
+// Which SIMD the dispatcher put each of a 512-thread workgroup's eight waves on (HW_ID bits 5:4), launched with the fused T63
+// kernels' LDS footprint, i.e. one workgroup per CU as they run.  The T63 kernels place their Legendre and FFT waves by SIMD
+// on the assumption that hardware waves w and w + 4 share one (round-robin placement): spdy_wave_placement checks it.
+__global__ __launch_bounds__(512) void wave_placement_kernel(int *out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);      // hwreg(HW_REG_HW_ID, 4, 2) = SIMD_ID
+    if ((threadIdx.x & 63) == 0) {
+        lds[threadIdx.x >> 6] = 0.0;                                                // (the allocation is really made)
+        out[8 * blockIdx.x + (threadIdx.x >> 6)] = (int)simd;
+    }
+}
+hipError_t launch_wave_placement(int *d_out, int nwg, hipStream_t s)
+{
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wave_placement_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, t63::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        once = true;
+    }
+    hipLaunchKernelGGL(wave_placement_kernel, dim3(nwg), dim3(512), t63::LDS_BYTES, s, d_out);
+    return hipGetLastError();
+}
+
+
 }  // namespace spdy

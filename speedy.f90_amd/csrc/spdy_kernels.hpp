@@ -84,6 +84,8 @@ hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const 
                             hipStream_t s, const double *grid2 = nullptr, double *spec2 = nullptr, int nplain = 0,
                             const double *grid_p = nullptr, double *spec_p = nullptr);
 
+// SIMD of each of the eight waves of nwg workgroups shaped like the fused T63 kernels' (d_out: 8 ints per workgroup)
+hipError_t launch_wave_placement(int *d_out, int nwg, hipStream_t s);
 // Fused T63 kernels: a pair of fields per tile, six latitude chunks, accumulators / B operands resident in VGPRs
 hipError_t launch_s2g_fused_t63(const DevPlan &p, int nb, const double *spec, const int *d_kcos, int kcos_all, double *grid, int max_wg,
                                 hipStream_t s);

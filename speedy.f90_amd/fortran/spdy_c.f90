@@ -325,6 +325,12 @@ module spdy_c
             integer(c_int), intent(out) :: launches(*)
             integer(c_int) :: rc
         end function
+        function spdy_wave_placement(plan, simd_of_wave, violations) bind(C, name="spdy_wave_placement") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int), intent(out) :: simd_of_wave(8), violations
+            integer(c_int) :: rc
+        end function
         function spdy_plan_dims(plan, dims) bind(C, name="spdy_plan_dims") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: plan

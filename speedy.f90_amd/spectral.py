@@ -293,6 +293,14 @@ class Spectral:
         """1 / -1 (default) = fused single-pass kernels (T30, T63) at every batch size, 0 = four-kernel path."""
         check(self.lib.spdy_plan_set_fused(self.h, int(mode)))
 
+    def wave_placement(self):
+        """(SIMD of waves 0..7 of workgroup 0, number of workgroups that violate the round-robin placement the T63 kernels'
+        role assignment relies on) -- spdy_wave_placement."""
+        import ctypes
+        simd, bad = (ctypes.c_int * 8)(), ctypes.c_int(0)
+        check(self.lib.spdy_wave_placement(self.h, simd, ctypes.byref(bad)))
+        return list(simd), bad.value
+
     def set_profiling(self, on=True):
         check(self.lib.spdy_plan_set_profiling(self.h, 1 if on else 0))
 

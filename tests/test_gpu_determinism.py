@@ -52,3 +52,17 @@ def test_repeatable_and_position_independent(res, fused, sizes):
         sp.grid_to_spec_dev(G[nb - 1:nb], one_s); sp.spec_to_grid_dev(one_s, one_g, kcos=2); sp.synchronize()
         assert torch.equal(runs[0][0][nb - 1:nb], one_s) and torch.equal(runs[0][1][nb - 1:nb], one_g)
     sp.close()
+
+
+def test_wave_placement_assumption():
+    """The fused T63 kernels give their Legendre (matrix-core) and FFT waves separate SIMDs by hardware wave index, assuming the
+    dispatcher places the eight waves of a 512-thread workgroup round-robin -- waves w and w + 4 on one SIMD (measured faster, and
+    with the roles mixed on a SIMD the inverse kernel has been seen to return timing-dependent wrong values: T63_ROLE_MIX in
+    csrc/spdy_fused_t63.inc).  spdy_wave_placement reads the SIMD id of every wave of one such workgroup per CU."""
+    import speedy_f90_amd as s
+    sp = s.Spectral("t63", kx=8, max_batch=4, device=0)
+    for _ in range(3):
+        simd, bad = sp.wave_placement()
+        assert bad == 0, (simd, bad)
+        assert simd[:4] == simd[4:] and sorted(simd[:4]) == [0, 1, 2, 3], simd
+    sp.close()
