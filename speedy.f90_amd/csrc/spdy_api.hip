@@ -320,6 +320,7 @@ int ensure_four(spdy_plan *p)
 int ensure_staging(spdy_plan *p, size_t elems)
 {
     NOT_CAPTURING(p, "a host-pointer entry point");
+    p->pending.clear();               // (a call that failed between its d2h and its sync must not leave copies behind)
     if (!p->dstage[0]) {
         // four buffers big enough for max_batch grids (the largest array kind)
         p->stage_elems = (size_t)p->max_batch * p->tab.il * p->tab.ix;
