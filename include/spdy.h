@@ -114,8 +114,8 @@ int spdy_plan_get_profile(spdy_plan *plan, double *ms, int *launches);
 /* Diagnostic: where the dispatcher places the eight waves of a workgroup shaped like the fused T63 kernels' (512 threads,
  * their LDS footprint, one workgroup per CU).  simd_of_wave[0..7] = SIMD of waves 0..7 of workgroup 0; violations = how many of
  * the launch's workgroups (one per CU) do NOT have waves w and w + 4 on one SIMD and waves 0..3 on four different ones.  The
- * T63 kernels assign their two wave roles by SIMD on that assumption (csrc/spdy_fused_t63.inc: faster, and the inverse
- * kernel has been seen to misbehave with the roles mixed on a SIMD); tests/test_gpu_determinism.py checks violations == 0. */
+ * T63 kernels assign their two wave roles to SIMDs on that assumption (csrc/spdy_fused_t63.inc: a tuning choice per kernel,
+ * results do not depend on it); tests/test_gpu_determinism.py checks violations == 0.                                      */
 int spdy_wave_placement(spdy_plan *plan, int *simd_of_wave, int *violations);
 /* dims[0..7] = trunc, ix, iy, il, kx, nx, mx, max_batch */
 int spdy_plan_dims(const spdy_plan *plan, int *dims);

@@ -56,9 +56,9 @@ def test_repeatable_and_position_independent(res, fused, sizes):
 
 def test_wave_placement_assumption():
     """The fused T63 kernels give their Legendre (matrix-core) and FFT waves separate SIMDs by hardware wave index, assuming the
-    dispatcher places the eight waves of a 512-thread workgroup round-robin -- waves w and w + 4 on one SIMD (measured faster, and
-    with the roles mixed on a SIMD the inverse kernel has been seen to return timing-dependent wrong values: T63_ROLE_MIX in
-    csrc/spdy_fused_t63.inc).  spdy_wave_placement reads the SIMD id of every wave of one such workgroup per CU."""
+    dispatcher places the eight waves of a 512-thread workgroup round-robin -- waves w and w + 4 on one SIMD (the inverse kernel
+    keeps its Legendre and FFT waves on separate SIMDs, the direct kernel pairs one of each per SIMD: both measured faster that
+    way, csrc/spdy_fused_t63.inc).  spdy_wave_placement reads the SIMD id of every wave of one such workgroup per CU."""
     import speedy_f90_amd as s
     sp = s.Spectral("t63", kx=8, max_batch=4, device=0)
     for _ in range(3):

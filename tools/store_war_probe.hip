@@ -52,7 +52,33 @@ __global__ __launch_bounds__(512) void probe(int placement, int iters, int nt, u
             u4 d0, d1, d2, d3;
             // four register sets: load pattern A into all, then store each and immediately reload it with pattern B (the burst of
             // a copy-out: several 1 KB stores queued behind each other, every one followed by a load into its data registers)
-            if (nt)
+            if (nt >= 2) {
+                // the OTHER overwrite the compiler emits: a VALU write to one data dword in the instruction after the store.
+                // nt = 2: soffset in an SGPR (the compiler inserts no wait state for this form); nt = 3: the offset in the
+                // VGPR and soffset = 0 (the form for which it inserts one s_nop -- written out here)
+                const unsigned vo2 = voff + soff;
+                if (nt == 2)
+                    asm volatile("ds_read_b128 v[20:23], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen\n\tv_add_u32 v22, 0xB0000000, %1\n\t"
+                                 "ds_read_b128 v[24:27], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[24:27], %1, %2, %3 offen offset:1024\n\tv_add_u32 v24, 0xB0000000, %1\n\t"
+                                 "ds_read_b128 v[20:23], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[20:23], %1, %2, %3 offen offset:2048\n\tv_add_u32 v23, 0xB0000000, %1\n\t"
+                                 "ds_read_b128 v[24:27], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[24:27], %1, %2, %3 offen offset:3072\n\tv_add_u32 v25, 0xB0000000, %1"
+                                 :: "v"(ldsA), "v"(voff), "s"(rsrc), "s"(soff) : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "memory");
+                else
+                    asm volatile("ds_read_b128 v[20:23], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen\n\ts_nop 0\n\tv_add_u32 v22, 0xB0000000, %1\n\t"
+                                 "ds_read_b128 v[24:27], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[24:27], %1, %2, 0 offen offset:1024\n\ts_nop 0\n\tv_add_u32 v24, 0xB0000000, %1\n\t"
+                                 "ds_read_b128 v[20:23], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[20:23], %1, %2, 0 offen offset:2048\n\ts_nop 0\n\tv_add_u32 v23, 0xB0000000, %1\n\t"
+                                 "ds_read_b128 v[24:27], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
+                                 "buffer_store_dwordx4 v[24:27], %1, %2, 0 offen offset:3072\n\ts_nop 0\n\tv_add_u32 v25, 0xB0000000, %1"
+                                 :: "v"(ldsA), "v"(vo2), "s"(rsrc) : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "memory");
+                d0 = d1 = d2 = d3 = u4{0, 0, 0, 0};
+            } else if (nt)
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4\n\ts_waitcnt lgkmcnt(0)\n\t"
                              "buffer_store_dwordx4 %0, %5, %6, %7 offen nt\n\tds_read_b128 %0, %8\n\t"
                              "buffer_store_dwordx4 %1, %5, %6, %7 offen offset:1024 nt\n\tds_read_b128 %1, %8\n\t"
@@ -81,7 +107,7 @@ int main(int argc, char **argv)
     hipMemset(table, 1, (size_t)nwg * 4096 * sizeof(u4));
     hipFuncSetAttribute((const void *)probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     std::vector<u4> h(nout);
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 4; ++nt)
         for (int placement = 0; placement < 3; ++placement)
             for (int rep = 0; rep < 2; ++rep) {
                 hipMemset(out, 0, nout * sizeof(u4));
@@ -97,8 +123,8 @@ int main(int argc, char **argv)
                         if (e[j] != want) { ++bad; if ((e[j] >> 28) == 0xB) ++badB; ++lanes[lane]; }
                     }
                 }
-                printf("%s stores, placement %d (%s): %zu wrong dwords of %zu (%zu hold the LATER load's pattern) %s",
-                       nt ? "nt" : "plain", placement, placement == 0 ? "loader + worker on every SIMD" : placement == 1 ? "roles by SIMD" : "no loaders",
+                printf("%s, placement %d (%s): %zu wrong dwords of %zu (%zu hold the LATER load's pattern) %s",
+                       nt == 0 ? "store + LDS load, plain stores" : nt == 1 ? "store + LDS load, nt stores" : nt == 2 ? "store (SGPR soffset) + VALU write" : "store (soffset 0) + s_nop 0 + VALU write", placement, placement == 0 ? "loader + worker on every SIMD" : placement == 1 ? "roles by SIMD" : "no loaders",
                        bad, nout * 4, badB, hipGetErrorString(hipGetLastError()));
                 if (bad) { printf("  lanes:"); for (int l = 0; l < 64; ++l) if (lanes[l]) printf(" %d", l); }
                 printf("\n");
