@@ -12,13 +12,13 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define STR2(x) #x
 #define STR(x) STR2(x)
 #define LOADA "ds_read_b128 v[20:23], %0\n\ts_waitcnt lgkmcnt(0)\n\t"
-#define CLOB "v20", "v21", "v22", "v23", "memory"
+#define CLOB "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "memory"
 
 // KIND 0: buffer store, SGPR soffset; 1: buffer store, soffset 0 (offset in the VGPR); 2: global store.  NOPS < 0: no s_nop at all
 template <int KIND, int NOPS>
 __global__ __launch_bounds__(512) void probe(u4 *out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned lds[512];
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lds[threadIdx.x] = (threadIdx.x < 256 ? 0xA0000000u : 0xB0000000u) | (unsigned)(threadIdx.x & 255);
     __syncthreads();
@@ -43,6 +43,23 @@ __global__ __launch_bounds__(512) void probe(u4 *out)
         else if (NOPS == 5) asm volatile(LOADA storeasm "\n\t" NOPSTR(5) "v_add_u32 v22, 0xB0000000, %1" :: __VA_ARGS__ : CLOB); \
         else if (NOPS == 7) asm volatile(LOADA storeasm "\n\t" NOPSTR(7) "v_add_u32 v22, 0xB0000000, %1" :: __VA_ARGS__ : CLOB); \
         else asm volatile(LOADA storeasm "\n\t" NOPSTR(15) "v_add_u32 v22, 0xB0000000, %1" :: __VA_ARGS__ : CLOB);
+        if (KIND == 3) {
+            // burst: four 1 KB stores behind each other (two register sets), each followed by N wait states and a VALU write to
+            // one of its data dwords -- the copy-out of a transform kernel
+            if ((i & 3) == 0) {
+#define GRP(regs, r, off, nopstr) "ds_read_b128 " regs ", %0\n\ts_waitcnt lgkmcnt(0)\n\tbuffer_store_dwordx4 " regs ", %1, %2, %3 offen offset:" off "\n\t" nopstr "v_add_u32 " r ", 0xB0000000, %1\n\t"
+#define BURST(nopstr) asm volatile(GRP("v[20:23]", "v22", "0", nopstr) GRP("v[24:27]", "v24", "1024", nopstr) GRP("v[20:23]", "v23", "2048", nopstr) GRP("v[24:27]", "v25", "3072", nopstr) \
+                                   :: "v"(ldsA), "v"(voff), "s"(rsrc), "s"(soff) : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "memory")
+                if (NOPS < 0) BURST("");
+                else if (NOPS == 0) BURST("s_nop 0\n\t");
+                else if (NOPS == 1) BURST("s_nop 1\n\t");
+                else if (NOPS == 2) BURST("s_nop 2\n\t");
+                else if (NOPS == 3) BURST("s_nop 3\n\t");
+                else if (NOPS == 5) BURST("s_nop 5\n\t");
+                else if (NOPS == 7) BURST("s_nop 7\n\t");
+                else BURST("s_nop 15\n\t");
+            }
+        } else
         if (KIND == 0) { BODY("buffer_store_dwordx4 v[20:23], %1, %2, %3 offen", "v"(ldsA), "v"(voff), "s"(rsrc), "s"(soff)) }
         else if (KIND == 1) { BODY("buffer_store_dwordx4 v[20:23], %1, %2, 0 offen", "v"(ldsA), "v"(vo2), "s"(rsrc)) }
         else { BODY("global_store_dwordx4 %2, v[20:23], off", "v"(ldsA), "v"(voff), "v"(gp)) }
@@ -55,7 +72,9 @@ static void run(u4 *out, std::vector<u4> &h, size_t nout)
     size_t bad = 0, lanes[64] = {0};
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(out, 0, nout * sizeof(u4));
-        hipLaunchKernelGGL((probe<KIND, NOPS>), dim3(256), dim3(512), 0, 0, out);
+        // the transform kernels' footprint: one workgroup per CU, two waves per SIMD
+        hipFuncSetAttribute((const void *)probe<KIND, NOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+        hipLaunchKernelGGL((probe<KIND, NOPS>), dim3(256), dim3(512), 150000, 0, out);
         hipDeviceSynchronize();
         hipMemcpy(h.data(), out, nout * sizeof(u4), hipMemcpyDeviceToHost);
         for (size_t i = 0; i < nout; ++i) {
@@ -63,7 +82,7 @@ static void run(u4 *out, std::vector<u4> &h, size_t nout)
             for (int j = 0; j < 4; ++j) if (e[j] != (0xA0000000u | (4 * lane + j))) { ++bad; ++lanes[lane]; }
         }
     }
-    printf("%-38s %-22s: %8zu wrong dwords of %zu", KIND == 0 ? "buffer store, SGPR soffset" : KIND == 1 ? "buffer store, soffset 0" : "global store",
+    printf("%-38s %-22s: %8zu wrong dwords of %zu", KIND == 0 ? "buffer store, SGPR soffset" : KIND == 1 ? "buffer store, soffset 0" : KIND == 2 ? "global store" : "buffer stores, SGPR soffset, bursts of 4",
            NOPS < 0 ? "VALU write next" : NOPS == 0 ? "s_nop 0 (1 wait state)" : NOPS == 1 ? "s_nop 1" : NOPS == 2 ? "s_nop 2" : NOPS == 3 ? "s_nop 3" : NOPS == 5 ? "s_nop 5" : NOPS == 7 ? "s_nop 7" : "s_nop 15", bad, 2 * nout * 4);
     if (bad) { printf("   lanes:"); for (int l = 0; l < 64; ++l) if (lanes[l]) printf(" %d", l); }
     printf("\n");
@@ -75,6 +94,6 @@ int main()
     u4 *out; hipMalloc(&out, nout * sizeof(u4));
     std::vector<u4> h(nout);
 #define ALLN(K) run<K, -1>(out, h, nout); run<K, 0>(out, h, nout); run<K, 1>(out, h, nout); run<K, 2>(out, h, nout); run<K, 3>(out, h, nout); run<K, 5>(out, h, nout); run<K, 7>(out, h, nout); run<K, 15>(out, h, nout);
-    ALLN(0) ALLN(1) ALLN(2)
+    ALLN(0) ALLN(1) ALLN(2) ALLN(3)
     return 0;
 }
