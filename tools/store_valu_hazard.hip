@@ -43,6 +43,14 @@ __global__ __launch_bounds__(512) void probe(u4 *out)
         else if (NOPS == 5) asm volatile(LOADA storeasm "\n\t" NOPSTR(5) "v_add_u32 v22, 0xB0000000, %1" :: __VA_ARGS__ : CLOB); \
         else if (NOPS == 7) asm volatile(LOADA storeasm "\n\t" NOPSTR(7) "v_add_u32 v22, 0xB0000000, %1" :: __VA_ARGS__ : CLOB); \
         else asm volatile(LOADA storeasm "\n\t" NOPSTR(15) "v_add_u32 v22, 0xB0000000, %1" :: __VA_ARGS__ : CLOB);
+        if (KIND == 4) {
+            // the LDS analogue: ds_write_b128 of v[20:23], N wait states, VALU write to v22; the cell is read back and copied out
+            const unsigned ldsD = 4096u + 16u * threadIdx.x;
+#define LDSBODY(nopstr) asm volatile(LOADA "ds_write_b128 %1, v[20:23]\n\t" nopstr "v_add_u32 v22, 0xB0000000, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(ldsA), "v"(ldsD) : "v20", "v21", "v22", "v23", "memory")
+            if (NOPS < 0) LDSBODY(""); else if (NOPS == 0) LDSBODY("s_nop 0\n\t"); else if (NOPS == 1) LDSBODY("s_nop 1\n\t"); else LDSBODY("s_nop 3\n\t");
+            const u4 back = *reinterpret_cast<const u4 *>(reinterpret_cast<const char *>(lds) + ldsD);
+            gp[0] = back;
+        } else
         if (KIND == 3) {
             // burst: four 1 KB stores behind each other (two register sets), each followed by N wait states and a VALU write to
             // one of its data dwords -- the copy-out of a transform kernel
@@ -82,7 +90,7 @@ static void run(u4 *out, std::vector<u4> &h, size_t nout)
             for (int j = 0; j < 4; ++j) if (e[j] != (0xA0000000u | (4 * lane + j))) { ++bad; ++lanes[lane]; }
         }
     }
-    printf("%-38s %-22s: %8zu wrong dwords of %zu", KIND == 0 ? "buffer store, SGPR soffset" : KIND == 1 ? "buffer store, soffset 0" : KIND == 2 ? "global store" : "buffer stores, SGPR soffset, bursts of 4",
+    printf("%-38s %-22s: %8zu wrong dwords of %zu", KIND == 0 ? "buffer store, SGPR soffset" : KIND == 1 ? "buffer store, soffset 0" : KIND == 2 ? "global store" : KIND == 3 ? "buffer stores, SGPR soffset, bursts of 4" : "LDS store (ds_write_b128)",
            NOPS < 0 ? "VALU write next" : NOPS == 0 ? "s_nop 0 (1 wait state)" : NOPS == 1 ? "s_nop 1" : NOPS == 2 ? "s_nop 2" : NOPS == 3 ? "s_nop 3" : NOPS == 5 ? "s_nop 5" : NOPS == 7 ? "s_nop 7" : "s_nop 15", bad, 2 * nout * 4);
     if (bad) { printf("   lanes:"); for (int l = 0; l < 64; ++l) if (lanes[l]) printf(" %d", l); }
     printf("\n");
@@ -95,5 +103,6 @@ int main()
     std::vector<u4> h(nout);
 #define ALLN(K) run<K, -1>(out, h, nout); run<K, 0>(out, h, nout); run<K, 1>(out, h, nout); run<K, 2>(out, h, nout); run<K, 3>(out, h, nout); run<K, 5>(out, h, nout); run<K, 7>(out, h, nout); run<K, 15>(out, h, nout);
     ALLN(0) ALLN(1) ALLN(2) ALLN(3)
+    run<4, -1>(out, h, nout); run<4, 0>(out, h, nout); run<4, 1>(out, h, nout);
     return 0;
 }
