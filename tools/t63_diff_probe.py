@@ -26,11 +26,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         sp.synchronize()
         res.append(o.cpu().numpy().copy())
     np.save(out, np.stack(res))
-    if hasattr(sp.lib, "spdy_debug_t63_verify"):      # -DT63_EXP_VERIFY builds: LDS cells whose read-back differed from the written register
-        import ctypes
-        v = (ctypes.c_ulonglong * 4)()
-        sp.lib.spdy_debug_t63_verify(v, 1)
-        print("   verify counters (first read-back mismatches, second read-back mismatches, waves checked):", list(v)[:3])
     sys.exit(0)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 reps = 4
