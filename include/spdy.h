@@ -258,23 +258,73 @@ int spdy_direct_batch_spectral_step_dev(spdy_plan *plan, const double *d_ug, con
                                         double *ps, const double *phis, const double *d_tcorh, const double *d_qcorh, double sdrag,
                                         int j1, double dt, double eps, double wil, double *phi);
 
-/* ---- multi-GPU: the one exchange a level-sharded step needs (one process per GPU, RCCL over xGMI) ------------
- * The transform batch shards over (field x level) with no communication.  implicit_terms couples all levels of a
- * coefficient (implicit.f90:174-216), so ranks that own level blocks complete each other's divdt/tdt first.
- * Rank r of n owns levels [nlev*r/n, nlev*(r+1)/n) (spdy_comm_level_range).  Rank 0 obtains an id with
+/* ---- multi-GPU: level-sharded time steps (one process per GPU with RCCL over xGMI, or ranks inside one process) -------
+ * The transform batch shards over (field x level) with no communication.  What couples levels in a step is exchanged:
+ * implicit_terms' operands (implicit.f90:174-216) with spdy_implicit_terms_sharded_dev, or -- the complete adiabatic step --
+ * everything the two column kernels read, with spdy_sharded_step_dev below.
+ * Rank r of n owns levels [nlev*r/n, nlev*(r+1)/n) (spdy_comm_level_range).  RCCL ranks: rank 0 obtains an id with
  * spdy_comm_unique_id and hands the SPDY_COMM_ID_BYTES bytes to the other ranks by whatever means the host has
  * (MPI_Bcast, a file, torch.distributed); then every rank calls spdy_comm_create.  Collectives run on the plan's
  * stream and can be captured into a graph.  RCCL is loaded on first use.                                        */
 typedef struct spdy_comm spdy_comm;
-enum { SPDY_COMM_ID_BYTES = 128 };
+enum { SPDY_COMM_ID_BYTES = 128, SPDY_COMM_MAX_ARRAYS = 16 };
 int spdy_comm_unique_id(char *id);
 int spdy_comm_create(spdy_plan *plan, int nranks, int rank, const char *id, spdy_comm **comm);
 int spdy_comm_destroy(spdy_comm *comm);
 int spdy_comm_level_range(const spdy_comm *comm, int nlev, int *lo, int *hi);
-/* in place: d_full[i] are narr full (mx,nx,nlev) stacks in which this rank has filled its own level block */
+/* Ranks INSIDE one process -- a single-process host (the reference is one: speedy.f90:24-54) that drives several GPUs, one
+ * host thread and one plan per GPU; also how the multi-rank paths are tested on a 1-GPU box (several plans on one device).
+ * No RCCL: a collective blocks its calling thread until every rank of the group has entered it and moves the blocks with
+ * device-to-device / peer copies on the ranks' own streams.  The calls of different ranks must come from different threads;
+ * a rank missing for $SPDY_COMM_TIMEOUT_S (default 120) seconds breaks the group (SPDY_ERR_COMM) instead of hanging it.
+ * Not graph-capturable (SPDY_ERR_STATE inside a capture).  Everything else -- level ranges, spdy_allgather_levels_dev, the
+ * sharded step -- is the same code as with RCCL ranks.                                                                 */
+typedef struct spdy_comm_group spdy_comm_group;
+int spdy_comm_group_create(int nranks, spdy_comm_group **group);
+int spdy_comm_group_destroy(spdy_comm_group *group);      /* after the group's communicators (SPDY_ERR_STATE otherwise) */
+int spdy_comm_create_local(spdy_plan *plan, spdy_comm_group *group, int rank, spdy_comm **comm);
+/* in place: d_full[i] are narr <= SPDY_COMM_MAX_ARRAYS full (mx,nx,nlev) stacks in which this rank has filled its own level block */
 int spdy_allgather_levels_dev(spdy_comm *comm, int nlev, int narr, double *const *d_full);
-/* all-gather of the level blocks of divdt and tdt, then implicit_terms on the full columns (every rank) */
+/* all-gather of the level blocks of divdt and tdt, then implicit_terms on the full columns (every rank).  psdt must already be
+ * the complete surface-pressure tendency on every rank -- true for implicit_terms called on its own, NOT inside a level-sharded
+ * step, where get_spectral_tendencies (tendencies.f90:256-263) first sums the divergence of all levels into it.        */
 int spdy_implicit_terms_sharded_dev(spdy_comm *comm, double *divdt, double *tdt, double *psdt);
+
+/* The COMPLETE adiabatic time step with the transforms sharded by level (BASELINE config 3).  Lines of the reference that couple
+ * levels: get_grid_point_tendencies' vertical means, sigma-dot sums and half-level fluxes (tendencies.f90:109-197),
+ * get_spectral_tendencies' dmean / sigma-dot sums and psdt -= dmean (:256-285), the hydrostatic integration
+ * (geopotential.f90:33-57), implicit_terms (implicit.f90:174-216).  Rank r runs the inverse and the direct transforms of ITS
+ * levels only; the two column kernels run on full columns on every rank, each behind ONE in-place all-gather:
+ *     inverse batch (own levels of time level j2; + grad(ps), level-free and replicated)  ->  all-gather of the gridded
+ *     prognostics (6 kx grids)  ->  grid tendencies (full columns in, own levels' direct-batch operands out)  ->  direct batch
+ *     (own levels; + the level-free ps tendency)  ->  all-gather of the spectral tendencies (9 kx + nranks spectra)  ->
+ *     spectral step on full columns: tendency combination, get_spectral_tendencies, implicit_terms, diffusion, leapfrog.
+ * Every rank holds the full prognostic state (vor, div, t, tr: (mx,nx,kx,2); ps: (mx,nx,2)) before and after; no rank reads a
+ * level of an intermediate field that it neither computed nor received.  The exchanged stacks are stored block by block, one
+ * contiguous block per rank (csrc/spdy_kernels.hpp: LevelShard), in workspace the communicator owns
+ * (spdy_sharded_step_workspace: allocate before a graph capture).  kx <= 16, nranks <= kx, max_batch >= 4 kx + 2.
+ * Results: the transforms are position-independent and the column kernels evaluate the unsharded kernels' expressions, so the
+ * step agrees with spdy_inverse_batch_segs_dev + spdy_grid_tendencies_dev + spdy_direct_batch_spectral_step_dev to rounding
+ * (in practice bit for bit, tests/test_gpu_sharded_step.py) for every rank count.
+ *   spdy_sharded_step_dev          the whole step; tend_out (4 kx + 1 spectra: vordt | divdt | tdt | trdt | psdt, truncated, as
+ *                                  step_field_* leaves them) may be NULL
+ *   spdy_sharded_step_grid_dev     first half, up to the grid tendencies ...
+ *   spdy_sharded_step_operands     ... whose results -- this rank's levels [lo, hi): u, v [3 nl], plain [3 nl + 1] grids laid
+ *                                  out as spdy_grid_tendencies_dev documents, with nl for kx -- a host with physics updates in
+ *                                  place (tendencies.f90:203-206) before ...
+ *   spdy_sharded_step_spectral_dev ... the second half
+ *   spdy_sharded_step_stacks       the two exchanged stacks (tests poison them between steps)                              */
+int spdy_sharded_step_workspace(spdy_comm *comm);
+int spdy_sharded_step_dev(spdy_comm *comm, double *vor, double *div, double *t, double *tr, double *ps, const double *phis,
+                          const double *d_tcorh, const double *d_qcorh, double sdrag, int j1, int j2, double dt, double eps, double wil,
+                          double *phi, double *tend_out);
+int spdy_sharded_step_grid_dev(spdy_comm *comm, const double *vor, const double *div, const double *t, const double *tr,
+                               const double *ps, int j2);
+int spdy_sharded_step_operands(spdy_comm *comm, double **u, double **v, double **plain, int *lo, int *hi);
+int spdy_sharded_step_spectral_dev(spdy_comm *comm, double *vor, double *div, double *t, double *tr, double *ps, const double *phis,
+                                   const double *d_tcorh, const double *d_qcorh, double sdrag, int j1, double dt, double eps, double wil,
+                                   double *phi, double *tend_out);
+int spdy_sharded_step_stacks(spdy_comm *comm, double **grid_stack, size_t *grid_doubles, double **spec_stack, size_t *spec_doubles);
 
 /* ---- fused operator + transform sequences (device-resident; extensions of the reference interface) ------
  * The reference's callers always follow uvspec by two spec_to_grid(.,2) (tendencies.f90:98-100, physics.f90:96-98)

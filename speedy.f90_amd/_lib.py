@@ -85,6 +85,17 @@ SIGNATURES = {
     "spdy_comm_level_range": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "spdy_allgather_levels_dev": [c_void_p, c_int, c_int, c_void_p],
     "spdy_implicit_terms_sharded_dev": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "spdy_comm_group_create": [c_int, ctypes.POINTER(c_void_p)],
+    "spdy_comm_group_destroy": [c_void_p],
+    "spdy_comm_create_local": [c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p)],
+    "spdy_sharded_step_workspace": [c_void_p],
+    "spdy_sharded_step_dev": [c_void_p] * 9 + [c_double, c_int, c_int, c_double, c_double, c_double, c_void_p, c_void_p],
+    "spdy_sharded_step_grid_dev": [c_void_p] * 6 + [c_int],
+    "spdy_sharded_step_operands": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                   ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
+    "spdy_sharded_step_spectral_dev": [c_void_p] * 9 + [c_double, c_int, c_double, c_double, c_double, c_void_p, c_void_p],
+    "spdy_sharded_step_stacks": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(c_void_p),
+                                 ctypes.POINTER(ctypes.c_size_t)],
     "spdy_grid_tendencies_dev": [c_void_p] * 12,
     "spdy_tendency_combine_dev": [c_void_p, c_void_p, c_void_p],
     "spdy_spectral_step_dev": [c_void_p] * 12 + [c_double, c_int, c_double, c_double, c_double, c_void_p],

@@ -455,16 +455,25 @@ template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 }  // namespace
 
 namespace spdy_detail {
-int direct_batch_raw63(spdy_plan *p, int npairs, const double *ug, const double *vg, int kcos, int nplain, const double *grid, double *spec)
+bool use_raw63(const spdy_plan *p, int npairs)
+{
+    return p->tab.trunc == 63 && p->fused_mode != 0 && p->tab.kx <= 16 && npairs <= p->max_batch && p->tab.implicit_ready && p->tab.sigma_ready;
+}
+
+int direct_batch_raw63(spdy_plan *p, int npairs, const double *ug, const double *vg, int kcos, int nplain, const double *grid, double *spec,
+                       double *raw_u, double *raw_v)
 {
     RC(check_batch(p, npairs));
     RC(check_batch(p, nplain));
-    RC(ensure_four(p));
+    if (!raw_u || !raw_v) {
+        RC(ensure_four(p));
+        raw_u = p->tmp_c; raw_v = p->tmp_d;
+    }
     const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
     spdy::T63Batch b{};
     b.nseg = 3;
-    b.seg[0] = spdy::T63Seg{ug, p->tmp_c, sc, nullptr, npairs, 1, 0, 0};
-    b.seg[1] = spdy::T63Seg{vg, p->tmp_d, sc, nullptr, npairs, 1, 0, 0};
+    b.seg[0] = spdy::T63Seg{ug, raw_u, sc, nullptr, npairs, 1, 0, 0};
+    b.seg[1] = spdy::T63Seg{vg, raw_v, sc, nullptr, npairs, 1, 0, 0};
     b.seg[2] = spdy::T63Seg{grid, spec, nullptr, nullptr, nplain, 1, 0, 0};
     return timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
 }

@@ -1,8 +1,6 @@
 // C ABI (include/spdy.h), second half: the spectral-space tail of a time step (horizontal diffusion, semi-implicit
-// solve, spectral tendencies, geopotential, leapfrog/RAW filter), the level all-gather over RCCL and the output path.
+// solve, spectral tendencies, geopotential, leapfrog/RAW filter) and the output path.  (Multi-GPU: spdy_api_shard.hip.)
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -342,190 +340,6 @@ int spdy_output_batch_dev(spdy_plan *p, const double *vor, const double *div, co
     }
     KERNEL(spdy::launch_output_cast(p->dev, c, p->stream));
     return SPDY_OK;
-}
-
-/* ---------------------------------------------------------------- level all-gather over RCCL (xGMI) */
-}  // extern "C"
-
-// RCCL is loaded on first use (dlopen by soname): single-GPU hosts never load it, and inside a process that already
-// carries a librccl.so.1 (e.g. PyTorch's) the same instance is shared instead of a second copy being mapped.
-namespace {
-struct Rccl {
-    void *handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    std::string error;
-};
-Rccl &rccl()
-{
-    static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names)
-        if ((r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
-    if (!r.handle) { r.error = std::string("cannot load librccl: ") + dlerror(); return r; }
-#define SYM(field, name)                                                                       \
-    if (!(r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name)))) { r.error = std::string("librccl lacks ") + name; r.handle = nullptr; return r; }
-    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
-    SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GroupStart, "ncclGroupStart")
-    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
-#undef SYM
-    return r;
-}
-}  // namespace
-
-struct spdy_comm {
-    spdy_plan *plan = nullptr;        // nullptr once the plan is gone: the communicator is then dead (SPDY_ERR_STATE)
-    ncclComm_t comm = nullptr;
-    int nranks = 1, rank = 0;
-    int force = 0;                    // $SPDY_COMM_FORCE (debug): 1 = issue the collectives even with one rank,
-                                      // 2 = ... and take the ragged (per-rank broadcast) route for equal blocks too
-};
-
-#define NCCL_TRY(expr)                                                                                     \
-    do {                                                                                                   \
-        ncclResult_t r_ = (expr);                                                                          \
-        if (r_ != ncclSuccess) return fail(SPDY_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
-    } while (0)
-// inside ncclGroupStart/End: the group is closed before the error is returned (an open group would swallow or hang every
-// later collective of the process)
-#define NCCL_GROUP_TRY(expr)                                                                               \
-    do {                                                                                                   \
-        ncclResult_t r_ = (expr);                                                                          \
-        if (r_ != ncclSuccess) {                                                                           \
-            (void)rccl().GroupEnd();                                                                       \
-            return fail(SPDY_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_));                 \
-        }                                                                                                  \
-    } while (0)
-
-namespace spdy_detail {
-// Plan teardown (spdy_plan_destroy, with the plan's stream still alive and idle): the plan's communicators are shut down and
-// detached; their handles stay valid for spdy_comm_destroy, every other call on them fails with SPDY_ERR_STATE.
-void release_comms(spdy_plan *p)
-{
-    for (spdy_comm *c : p->comms) {
-        if (c->comm && rccl().handle) (void)rccl().CommDestroy(c->comm);
-        c->comm = nullptr;
-        c->plan = nullptr;
-    }
-    p->comms.clear();
-}
-}  // namespace spdy_detail
-
-#define NEED_COMM(c)                                                                                       \
-    do {                                                                                                   \
-        if (!(c)) return fail(SPDY_ERR_ARG, "null comm");                                                  \
-        if (!(c)->plan) return fail(SPDY_ERR_STATE, "the communicator's plan has been destroyed");         \
-    } while (0)
-
-extern "C" {
-
-int spdy_comm_unique_id(char *id)
-{
-    static_assert(sizeof(ncclUniqueId) == SPDY_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
-    if (!id) return fail(SPDY_ERR_ARG, "null id");
-    if (!rccl().handle) return fail(SPDY_ERR_COMM, "%s", rccl().error.c_str());
-    ncclUniqueId u;
-    NCCL_TRY(rccl().GetUniqueId(&u));
-    std::memcpy(id, &u, sizeof(u));
-    return SPDY_OK;
-}
-
-int spdy_comm_create(spdy_plan *p, int nranks, int rank, const char *id, spdy_comm **comm)
-{
-    NEED_DEVICE(p);
-    if (!comm) return fail(SPDY_ERR_ARG, "null comm pointer");
-    *comm = nullptr;
-    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(SPDY_ERR_ARG, "bad rank %d of %d / null id", rank, nranks);
-    NOT_CAPTURING(p, "spdy_comm_create");
-    if (!rccl().handle) return fail(SPDY_ERR_COMM, "%s", rccl().error.c_str());
-    ncclUniqueId u;
-    std::memcpy(&u, id, sizeof(u));
-    spdy_comm *c = new spdy_comm;
-    c->plan = p; c->nranks = nranks; c->rank = rank;
-    if (const char *env = getenv("SPDY_COMM_FORCE")) c->force = atoi(env);
-    ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
-    if (r != ncclSuccess) {
-        delete c;
-        return fail(SPDY_ERR_COMM, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
-    }
-    p->comms.push_back(c);
-    *comm = c;
-    return SPDY_OK;
-}
-
-int spdy_comm_destroy(spdy_comm *c)
-{
-    if (!c) return SPDY_OK;
-    if (spdy_plan *p = c->plan) {                           // still attached: drain the plan's stream, then shut RCCL down
-        for (auto it = p->comms.begin(); it != p->comms.end(); ++it)
-            if (*it == c) { p->comms.erase(it); break; }
-        if (c->comm && rccl().handle) {
-            (void)hipSetDevice(p->device);
-            if (!p->capturing) (void)hipStreamSynchronize(p->stream);
-            (void)rccl().CommDestroy(c->comm);
-        }
-    }
-    delete c;
-    return SPDY_OK;
-}
-
-int spdy_comm_level_range(const spdy_comm *c, int nlev, int *lo, int *hi)
-{
-    if (!c || !lo || !hi || nlev < 0) return fail(SPDY_ERR_ARG, "bad argument");
-    *lo = (int)(((long)nlev * c->rank) / c->nranks);
-    *hi = (int)(((long)nlev * (c->rank + 1)) / c->nranks);
-    return SPDY_OK;
-}
-
-/* In place: every array d_full[i] is a full (mx,nx,nlev) stack of which this rank has filled its own level block
- * [lo, hi) (spdy_comm_level_range); afterwards every rank holds all levels.  One grouped RCCL operation for all
- * narr arrays, enqueued on the plan's stream (graph-capturable).  Equal blocks -> one-shot ncclAllGather per array
- * (each rank's block travels over its own xGMI link); ragged blocks -> one ncclBroadcast per rank and array.       */
-int spdy_allgather_levels_dev(spdy_comm *c, int nlev, int narr, double *const *d_full)
-{
-    NEED_COMM(c);
-    spdy_plan *p = c->plan;
-    NEED_DEVICE(p);
-    if (narr < 0 || narr > 8 || (narr && !d_full) || nlev < 0) return fail(SPDY_ERR_ARG, "bad argument");
-    for (int a = 0; a < narr; ++a)
-        if (!d_full[a]) return fail(SPDY_ERR_ARG, "null array %d", a);
-    if ((c->nranks == 1 && !c->force) || narr == 0 || nlev == 0) return SPDY_OK;
-    const size_t slab = spec_elems(p);                    // doubles per level
-    const bool even = nlev % c->nranks == 0 && c->force < 2;
-    NCCL_TRY(rccl().GroupStart());
-    for (int a = 0; a < narr; ++a) {
-        if (even) {
-            const size_t cnt = (size_t)(nlev / c->nranks) * slab;
-            NCCL_GROUP_TRY(rccl().AllGather(d_full[a] + (size_t)c->rank * cnt, d_full[a], cnt, ncclDouble, c->comm, p->stream));
-        } else {
-            for (int r = 0; r < c->nranks; ++r) {
-                const long lo = ((long)nlev * r) / c->nranks, hi = ((long)nlev * (r + 1)) / c->nranks;
-                if (hi > lo)
-                    NCCL_GROUP_TRY(rccl().Broadcast(d_full[a] + lo * slab, d_full[a] + lo * slab, (size_t)(hi - lo) * slab, ncclDouble, r,
-                                                    c->comm, p->stream));
-            }
-        }
-    }
-    NCCL_TRY(rccl().GroupEnd());
-    return SPDY_OK;
-}
-
-/* implicit_terms with the levels sharded over the ranks of `c` (implicit.f90:168-217 couples all levels of a
- * coefficient): gather the level blocks of divdt and tdt (psdt is level-free and identical on every rank), then the
- * solve on the full columns -- redundant on every rank, it is a few microseconds.                                */
-int spdy_implicit_terms_sharded_dev(spdy_comm *c, double *divdt, double *tdt, double *psdt)
-{
-    NEED_COMM(c);
-    double *arr[2] = {divdt, tdt};
-    RC(spdy_allgather_levels_dev(c, c->plan->tab.kx, 2, arr));
-    return spdy_implicit_terms_dev(c->plan, divdt, tdt, psdt);
 }
 
 }  // extern "C"

@@ -151,11 +151,23 @@ hipError_t launch_geopotential(const DevPlan &p, const double *t, const double *
 // get_spectral_tendencies (tendencies.f90:242-293); phi is written as the reference's module variable is
 hipError_t launch_spectral_tendencies(const DevPlan &p, const double *div, const double *t, const double *ps, const double *phis,
                                       double *divdt, double *tdt, double *psdt, double *phi, hipStream_t s);
+// Level-block layout of a level-sharded step (spdy_api_shard.hip).  Rank r of R owns the levels [kx r / R, kx (r + 1) / R)
+// = [lo_r, hi_r), nl_r of them.  A stack of F fields x kx levels that the ranks fill and exchange is stored block by block,
+// block r = the rank's own contiguous launch operands [F][nl_r] (+ X level-free fields behind them): its slab offset is
+// F lo_r + X r, and field f of level k lives at slab  F lo_r + X r + f nl_r + (k - lo_r)  of the owner r of k.  So ONE
+// contiguous block per rank travels in the exchange and every transform launch reads/writes plain contiguous stacks; only
+// the column kernels (grid tendencies, spectral step) index through the blocks.  nranks = 0: not sharded (the plain [F][kx]
+// stacks of separate pointers); with one rank the block layout coincides with the plain one.
+struct LevelShard { int nranks, rank; };
 // grid-space dynamical tendencies (tendencies.f90:105-197) and their spectral-space combination (:125-126, 218-233)
 struct GridTend {
     const double *ug, *vg, *tg, *vorg, *divg, *trg;   // [kx] grids each (vorg WITHOUT the Coriolis term)
     const double *px, *py;                            // grad(ps) on the grid
     double *u, *v, *plain;                            // [3 kx], [3 kx], [3 kx + 1] grids: operands of the direct batch
+    // sh.nranks >= 1: the six inputs are ONE level-block stack `ug` (F = 6, X = 0, field order ug, vg, vorg, divg, tg, trg:
+    // the other five pointers are ignored) holding all levels; the outputs are this rank's own launch operands only --
+    // u, v [3 nl], plain [3 nl + 1] with nl = the rank's level count (every rank gets the level-free last field)
+    LevelShard sh;
 };
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
 hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec, hipStream_t s);
@@ -170,6 +182,12 @@ struct SpecStep {
     // non-null: the vdspec pairs' spectra have NOT been through vds yet -- raw_u, raw_v [3kx] are grid_to_spec of the scaled
     // (u, v) grids and the kernel applies vds (spectral.f90:146-171) where it reads them (pvor / pdiv are outputs only)
     const double *raw_u, *raw_v;
+    // sh.nranks >= 1: the direct batches' outputs of all ranks are ONE level-block stack `pvor` (F = 9: the rank's pvor | pdiv
+    // | pspec stacks of 3 nl each, X = 1: its copy of the level-free psdt; pdiv / pspec / raw_u / raw_v are then only flags:
+    // raw_u non-null = the first six groups are the raw pairs' spectra) and the final tendencies go to tend_out
+    // [vordt | divdt | tdt | trdt] (kx each) | psdt in the plain layout instead of back into the operands
+    LevelShard sh;
+    double *tend_out;
 };
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s);
 // output path (input_output.f90:184-206)

@@ -72,9 +72,11 @@ int sync(spdy_plan *p);
 int ensure_staging(spdy_plan *p, size_t elems = (size_t)-1);
 inline bool on_host_stage(const spdy_plan *p) { return p->hstage[0] && p->stage_a == p->hstage[0]; }
 int ensure_four(spdy_plan *p);        // four-kernel path workspace
-// T63 fused path: the direct batch WITHOUT vds -- the scaled (u, v) grids' spectra go to p->tmp_c / p->tmp_d, the plain
-// grids' to spec (spdy_direct_batch_spectral_step_dev)
-int direct_batch_raw63(spdy_plan *p, int npairs, const double *ug, const double *vg, int kcos, int nplain, const double *grid, double *spec);
+// T63 fused path: the direct batch WITHOUT vds -- the scaled (u, v) grids' spectra go to raw_u / raw_v (null: p->tmp_c /
+// p->tmp_d), the plain grids' to spec (spdy_direct_batch_spectral_step_dev, the level-sharded step)
+int direct_batch_raw63(spdy_plan *p, int npairs, const double *ug, const double *vg, int kcos, int nplain, const double *grid, double *spec,
+                       double *raw_u = nullptr, double *raw_v = nullptr);
+bool use_raw63(const spdy_plan *p, int npairs);   // whether a step's direct batch of npairs (u, v) pairs takes that route
 int upload_level_tables(spdy_plan *p);
 void release_comms(spdy_plan *p);     // plan teardown: RCCL communicators of this plan are shut down, their handles stay valid but dead
 

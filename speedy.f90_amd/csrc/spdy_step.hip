@@ -351,7 +351,17 @@ __global__ void grid_tendencies_serial_kernel(DevPlan p, GridTend g)
 // (point, level) with the neighbouring levels read from LDS.  Expressions as in the reference's loops.
 // KM: level count bound of the instantiation (8 or 16); FULL: kx == KM, the level loops' guards fold (they are ONE wave's
 // instruction stream while the block waits, like the recurrences of the spectral step).
-template <int KM, bool FULL>
+// SH: level-sharded form (LevelShard, spdy_kernels.hpp): the six inputs come from ONE level-block stack that holds all levels,
+// the outputs are this rank's own levels only, laid out as ITS direct-batch operands.  Same expressions, same order.
+// Owner of level k among R ranks with blocks [kx r / R, kx (r + 1) / R): r = (R (k + 1) - 1) / kx.
+struct LevelBlock { int r, lo, nl; };
+__device__ __forceinline__ LevelBlock level_block(int k, int kx, int R)
+{
+    const int r = (R * (k + 1) - 1) / kx, lo = (kx * r) / R;
+    return LevelBlock{r, lo, (kx * (r + 1)) / R - lo};
+}
+
+template <int KM, bool FULL, bool SH>
 __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, GridTend g)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -365,8 +375,21 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
     double *stab = smean + 3 * BX;                                                                    // dhs[kx]
 #define LV(a_, k_) (a_)[(long)(k_) * gsz + i]
 #define S(b_, k_) (b_)[(k_) * BX + tx]
-    const double ug_c = LV(g.ug, k), vg_c = LV(g.vg, k), tg_c = LV(g.tg, k), tr_c = LV(g.trg, k), dv = LV(g.divg, k);
-    const double vor = LV(g.vorg, k) + p.coriol[j];                                        // (:103-107 coriolis)
+    // where this thread's level of input field f lives, and where (whether) its outputs go
+    int og = kx, ok = k, o_ps = 3 * kx;                                    // output group stride, level slot, slot of the level-free field
+    bool own = true;
+    double ug_c, vg_c, tg_c, tr_c, dv, vor_in;
+    if (SH) {
+        const LevelBlock b = level_block(k, kx, g.sh.nranks);
+        const long s0 = (long)6 * b.lo + (k - b.lo);                       // slab of (field 0, level k) in the F = 6 block stack
+        ug_c = LV(g.ug, s0); vg_c = LV(g.ug, s0 + b.nl); vor_in = LV(g.ug, s0 + 2 * b.nl); dv = LV(g.ug, s0 + 3 * b.nl);
+        tg_c = LV(g.ug, s0 + 4 * b.nl); tr_c = LV(g.ug, s0 + 5 * b.nl);
+        const int lo = (kx * g.sh.rank) / g.sh.nranks, hi = (kx * (g.sh.rank + 1)) / g.sh.nranks;
+        og = hi - lo; ok = k - lo; o_ps = 3 * og; own = k >= lo && k < hi;
+    } else {
+        ug_c = LV(g.ug, k); vg_c = LV(g.vg, k); tg_c = LV(g.tg, k); tr_c = LV(g.trg, k); dv = LV(g.divg, k); vor_in = LV(g.vorg, k);
+    }
+    const double vor = vor_in + p.coriol[j];                                               // (:103-107 coriolis)
     const double px = g.px[i], py = g.py[i], rgas = p.rgas, akap = p.akap;
     const double dhr = p.dhsr[k], trefk = p.tref[k];
     const double tgg = tg_c - trefk;                                                       // (:149)
@@ -405,7 +428,8 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
     }
     lds_sync();
     if (!valid) return;
-    if (k == 0) g.plain[(long)(3 * kx) * gsz + i] = (-umean) * px - vmean * py;            // (:125)
+    if (k == 0) g.plain[(long)o_ps * gsz + i] = (-umean) * px - vmean * py;                // (:125)
+    if (SH && !own) return;
     const double sig = S(ssig, k), sig1 = S(ssig, k + 1), sigm = S(ssigm, k), sigm1 = S(ssigm, k + 1);
     // fluxes temp(k) and temp(k+1) of the advected quantities (zero at the top level 1 and at kx+1: :152-153)
     double tu = 0.0, tv = 0.0, tt = 0.0, tq = 0.0, tu1 = 0.0, tv1 = 0.0, tt1 = 0.0, tq1 = 0.0;
@@ -423,14 +447,14 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
         tq1 = sig1 * (S(sq, k + 1) - tr_c);
         if (k + 1 == 1 || k + 1 == 2) tq1 = 0.0;
     }
-    LV(g.u, k) = vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr;                          // utend (:160-161)
-    LV(g.v, k) = -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr;                         // vtend (:170-171)
-    LV(g.plain, kx + k) = tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
-                          + akap * (tg_c * puv - tgg * dmean);                             // ttend (:181-184)
-    LV(g.plain, 2 * kx + k) = tr_c * dv - (tq1 + tq) * dhr;                                // trtend (:194)
-    LV(g.plain, k) = 0.5 * (ug_c * ug_c + vg_c * vg_c);                                    // kinetic energy (:220)
-    LV(g.u, kx + k) = -ug_c * tgg;  LV(g.v, kx + k) = -vg_c * tgg;                         // (:224)
-    LV(g.u, 2 * kx + k) = -ug_c * tr_c;  LV(g.v, 2 * kx + k) = -vg_c * tr_c;               // (:229)
+    LV(g.u, ok) = vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr;                         // utend (:160-161)
+    LV(g.v, ok) = -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr;                        // vtend (:170-171)
+    LV(g.plain, og + ok) = tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
+                           + akap * (tg_c * puv - tgg * dmean);                            // ttend (:181-184)
+    LV(g.plain, 2 * og + ok) = tr_c * dv - (tq1 + tq) * dhr;                               // trtend (:194)
+    LV(g.plain, ok) = 0.5 * (ug_c * ug_c + vg_c * vg_c);                                   // kinetic energy (:220)
+    LV(g.u, og + ok) = -ug_c * tgg;  LV(g.v, og + ok) = -vg_c * tgg;                       // (:224)
+    LV(g.u, 2 * og + ok) = -ug_c * tr_c;  LV(g.v, 2 * og + ok) = -vg_c * tr_c;             // (:229)
 #undef LV
 #undef S
 }
@@ -439,17 +463,25 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s)
 {
     const int gsz = p.ix * p.il;
+    if (g.sh.nranks >= 1 && (p.kx > 16 || g.sh.nranks > p.kx || g.sh.rank < 0 || g.sh.rank >= g.sh.nranks)) return hipErrorInvalidValue;
     if (p.kx > 16) hipLaunchKernelGGL(grid_tendencies_serial_kernel, dim3((gsz + 63) / 64), dim3(64), 0, s, p, g);
-    else {
+    else if (g.sh.nranks >= 1) {
+        const dim3 grd((gsz + GT_BX - 1) / GT_BX), blk(GT_BX, p.kx);
+        const size_t lds = grid_tendencies_lds(p.kx, GT_BX);
+        if (p.kx == 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, true, true>), grd, blk, lds, s, p, g);
+        else if (p.kx < 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, false, true>), grd, blk, lds, s, p, g);
+        else if (p.kx == 16) hipLaunchKernelGGL((grid_tendencies_kernel<16, true, true>), grd, blk, lds, s, p, g);
+        else hipLaunchKernelGGL((grid_tendencies_kernel<16, false, true>), grd, blk, lds, s, p, g);
+    } else {
         // 16 points x kx levels per block: at model sizes the kernel is a latency chain per block, and 4x as many (smaller)
         // blocks spread its LDS traffic and loads over 4x as many CUs (T30: 72 -> 288 blocks; T63 L16 step 92.3 -> 89.2 us)
         constexpr int bx = GT_BX;
         const dim3 grd((gsz + bx - 1) / bx), blk(bx, p.kx);
         const size_t lds = grid_tendencies_lds(p.kx, bx);
-        if (p.kx == 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, true>), grd, blk, lds, s, p, g);
-        else if (p.kx < 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, false>), grd, blk, lds, s, p, g);
-        else if (p.kx == 16) hipLaunchKernelGGL((grid_tendencies_kernel<16, true>), grd, blk, lds, s, p, g);
-        else hipLaunchKernelGGL((grid_tendencies_kernel<16, false>), grd, blk, lds, s, p, g);
+        if (p.kx == 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, true, false>), grd, blk, lds, s, p, g);
+        else if (p.kx < 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, false, false>), grd, blk, lds, s, p, g);
+        else if (p.kx == 16) hipLaunchKernelGGL((grid_tendencies_kernel<16, true, false>), grd, blk, lds, s, p, g);
+        else hipLaunchKernelGGL((grid_tendencies_kernel<16, false, false>), grd, blk, lds, s, p, g);
     }
     return hipGetLastError();
 }
@@ -489,7 +521,10 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // FULL: the level count IS the bound (8 or 16, the reference's and config 5's): every `kk < kx` guard and index clamp of the
 // unrolled level loops folds away.  The level recurrences are executed by ONE wave while the block waits, so their
 // instruction count (not a latency) is what the block pays: 1300 instructions at 4 cycles each were 2.7 us at kx = 16.
-template <int NJ, bool FULL>
+// SH: level-sharded form -- the direct batches' outputs of all ranks arrive as ONE level-block stack (LevelShard, F = 9, X = 1;
+// SpecStep::sh) and the final tendencies leave through tend_out in the plain layout; everything else (the prognostics, the
+// solve, the leapfrog) is on the full columns as ever, redundantly on every rank.  Same expressions, same order.
+template <int NJ, bool FULL, bool SH>
 __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecStep &a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];           // complex planes [kx][64]: divdt, tdt, phi / yf / d, div, t; + rows
@@ -512,7 +547,18 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     // critical path.
     const long lvl2 = (long)kx * sz;
     const cpx vor2 = ld(a.vor, lvl2 + i), div2 = ld(a.div, lvl2 + i), t2 = ld(a.t, lvl2 + i), tr2 = ld(a.tr, lvl2 + i);
-    const cpx ps2 = ld(a.ps, sz + ec), phs = ld(a.phis, ec), psdt_in = ld(a.pspec, (long)3 * kx * sz + ec);
+    // the direct batch's outputs: group f of stack X (A = pvor / raw_u, B = pdiv / raw_v, C = pspec) at this thread's level is
+    // element  (lv + f * L) + off_X  of pointer p_X.  Plain layout: three stacks [3 kx] with their own pointers.  Level-block
+    // layout: one pointer, block of this level's owner = [A | B | C] (3 nl each) + its copy of the level-free psdt.
+    long lv = (long)k * sz, L = (long)kx * sz, offB = 0, offC = 0, ipsdt = (long)3 * kx * sz + ec;
+    const double *pA = a.raw_u ? a.raw_u : a.pvor, *pB = a.raw_u ? a.raw_v : a.pdiv, *pC = a.pspec;
+    if (SH) {
+        const LevelBlock b = level_block(k, kx, a.sh.nranks);
+        lv = ((long)9 * b.lo + b.r + (k - b.lo)) * sz; L = (long)b.nl * sz; offB = 3 * L; offC = 6 * L;
+        ipsdt = (long)9 * (kx / a.sh.nranks) * sz + ec;                   // block 0 = [9 nl_0] + psdt, nl_0 = floor(kx / R)
+        pA = pB = pC = a.pvor;
+    }
+    const cpx ps2 = ld(a.ps, sz + ec), phs = ld(a.phis, ec), psdt_in = ld(pC, ipsdt);
     // ---- tendency combination on the direct batch's outputs
     cpx vordt, pd0, pd1, pd2;
     if (a.raw_u) {
@@ -520,12 +566,12 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         // transform kernel does not apply it): the expressions of vds_kernel (spdy_kernels.hip), row by row.  Every load is
         // unconditional at a clamped row; the rows the reference special-cases only choose among loaded values.
         const int nm = max(n - 1, 0), np = min(n + 1, p.nx - 1);
-        const long rm = (long)k * sz + nm * p.mx + m, rp = (long)k * sz + np * p.mx + m, L = (long)kx * sz;
+        const long i0 = lv + ec, rm = lv + nm * p.mx + m, rp = lv + np * p.mx + m;
         const double gx = p.gradx[m], dm = p.vddym[ec], dp = p.vddyp[ec];
-        const cpx u0 = ld(a.raw_u, i), u0m = ld(a.raw_u, rm), u0p = ld(a.raw_u, rp);
-        const cpx v0 = ld(a.raw_v, i), v0m = ld(a.raw_v, rm), v0p = ld(a.raw_v, rp);
-        const cpx u1 = ld(a.raw_u, L + i), v1m = ld(a.raw_v, L + rm), v1p = ld(a.raw_v, L + rp);
-        const cpx u2 = ld(a.raw_u, 2 * L + i), v2m = ld(a.raw_v, 2 * L + rm), v2p = ld(a.raw_v, 2 * L + rp);
+        const cpx u0 = ld(pA, i0), u0m = ld(pA, rm), u0p = ld(pA, rp);
+        const cpx v0 = ld(pB, offB + i0), v0m = ld(pB, offB + rm), v0p = ld(pB, offB + rp);
+        const cpx u1 = ld(pA, L + i0), v1m = ld(pB, offB + L + rm), v1p = ld(pB, offB + L + rp);
+        const cpx u2 = ld(pA, 2 * L + i0), v2m = ld(pB, offB + 2 * L + rm), v2p = ld(pB, offB + 2 * L + rp);
         auto vds_vor = [&](cpx um, cpx up, cpx v) {
             if (n == 0) return times_i(gx * v) - dp * up;
             if (n == p.nx - 1) return dm * um;
@@ -541,14 +587,14 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         pd1 = vds_div(v1m, v1p, u1);
         pd2 = vds_div(v2m, v2p, u2);
     } else {
-        vordt = ld(a.pvor, i);
-        pd0 = ld(a.pdiv, i);
-        pd1 = ld(a.pdiv, (long)kx * sz + i);
-        pd2 = ld(a.pdiv, (long)2 * kx * sz + i);
+        vordt = ld(pA, lv + ec);
+        pd0 = ld(pB, offB + lv + ec);
+        pd1 = ld(pB, offB + L + lv + ec);
+        pd2 = ld(pB, offB + 2 * L + lv + ec);
     }
-    cpx divdt = pd0 - p.el2[ec] * (-ld(a.pspec, i));
-    cpx tdt = pd1 + ld(a.pspec, (long)kx * sz + i);
-    cpx trdt = pd2 + ld(a.pspec, (long)2 * kx * sz + i);
+    cpx divdt = pd0 - p.el2[ec] * (-ld(pC, offC + lv + ec));
+    cpx tdt = pd1 + ld(pC, offC + L + lv + ec);
+    cpx trdt = pd2 + ld(pC, offC + 2 * L + lv + ec);
     // ---- get_spectral_tendencies (time level 1 of div, t, ps).  Every thread brings its own level of div and t into LDS (one
     // coalesced global round trip for the block); the three level recurrences -- vertical mean, sigma-dot prefix sum, the
     // hydrostatic integration -- are then short loops over LDS by ONE wave each (k = 0 and k = 1 run them side by side),
@@ -752,17 +798,25 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         st(f, off2 + idx, n2);
     };
     // (each thread reads back what it parked itself: no barrier needed)
-    stepf(a.vor, i, lvl2, vo, get(sl2, k), vordt, a.pvor, i);
-    stepf(a.div, i, lvl2, dv, get(sl2 + PL, k), divdt, a.pdiv, i);
-    stepf(a.t, i, lvl2, t1v, get(sl2 + 2 * PL, k), tdt, a.pdiv, (long)kx * sz + i);
-    stepf(a.tr, i, lvl2, tr1, get(sl2 + 3 * PL, k), trdt, a.pdiv, (long)2 * kx * sz + i);
-    if (k == 0) stepf(a.ps, ec, sz, ps1, get(sl2 + 4 * PL, 0), psdt, a.pspec, (long)3 * kx * sz + ec);
+    if (SH) {           // the operands are other ranks' blocks too (and, raw, neighbouring rows of other threads): tendencies leave apart
+        stepf(a.vor, i, lvl2, vo, get(sl2, k), vordt, a.tend_out, i);
+        stepf(a.div, i, lvl2, dv, get(sl2 + PL, k), divdt, a.tend_out, lvl2 + i);
+        stepf(a.t, i, lvl2, t1v, get(sl2 + 2 * PL, k), tdt, a.tend_out, 2 * lvl2 + i);
+        stepf(a.tr, i, lvl2, tr1, get(sl2 + 3 * PL, k), trdt, a.tend_out, 3 * lvl2 + i);
+        if (k == 0) stepf(a.ps, ec, sz, ps1, get(sl2 + 4 * PL, 0), psdt, a.tend_out, 4 * lvl2 + ec);
+    } else {
+        stepf(a.vor, i, lvl2, vo, get(sl2, k), vordt, a.pvor, i);
+        stepf(a.div, i, lvl2, dv, get(sl2 + PL, k), divdt, a.pdiv, i);
+        stepf(a.t, i, lvl2, t1v, get(sl2 + 2 * PL, k), tdt, a.pdiv, (long)kx * sz + i);
+        stepf(a.tr, i, lvl2, tr1, get(sl2 + 3 * PL, k), trdt, a.pdiv, (long)2 * kx * sz + i);
+        if (k == 0) stepf(a.ps, ec, sz, ps1, get(sl2 + 4 * PL, 0), psdt, a.pspec, (long)3 * kx * sz + ec);
+    }
     STEP_MARK(7);
 }
 
 // blocks of 16 x kx threads: NJ = 4 up to 8 levels, NJ = 8 up to 16 (two waves per SIMD: 260 blocks at T63 must not need two rounds)
-template <int NJ, bool FULL>
-__global__ __launch_bounds__(STEP_BX * 2 * NJ, NJ > 4 ? 2 : 1) void spectral_step_kernel(DevPlan p, SpecStep a) { spectral_step_body<NJ, FULL>(p, a); }
+template <int NJ, bool FULL, bool SH>
+__global__ __launch_bounds__(STEP_BX * 2 * NJ, NJ > 4 ? 2 : 1) void spectral_step_kernel(DevPlan p, SpecStep a) { spectral_step_body<NJ, FULL, SH>(p, a); }
 
 // Coefficients per block.  16 (x kx level rows): with 64 the T63 launch was 65 blocks of up to 1024 threads whose three
 // kx-term mat-vecs went through ONE CU's LDS each; 260 blocks of a quarter the size use the whole chip (captured step
@@ -776,10 +830,18 @@ hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t
     const int bx = spectral_step_bx(p);
     const size_t lds = spectral_step_lds(p.kx, bx);
     const dim3 grd((sz + bx - 1) / bx), blk(bx, p.kx);
-    if (p.kx == 8) hipLaunchKernelGGL((spectral_step_kernel<4, true>), grd, blk, lds, s, p, a);
-    else if (p.kx < 8) hipLaunchKernelGGL((spectral_step_kernel<4, false>), grd, blk, lds, s, p, a);
-    else if (p.kx == 16) hipLaunchKernelGGL((spectral_step_kernel<8, true>), grd, blk, lds, s, p, a);
-    else hipLaunchKernelGGL((spectral_step_kernel<8, false>), grd, blk, lds, s, p, a);
+    if (a.sh.nranks >= 1) {
+        if (a.sh.nranks > p.kx || !a.tend_out) return hipErrorInvalidValue;
+        if (p.kx == 8) hipLaunchKernelGGL((spectral_step_kernel<4, true, true>), grd, blk, lds, s, p, a);
+        else if (p.kx < 8) hipLaunchKernelGGL((spectral_step_kernel<4, false, true>), grd, blk, lds, s, p, a);
+        else if (p.kx == 16) hipLaunchKernelGGL((spectral_step_kernel<8, true, true>), grd, blk, lds, s, p, a);
+        else hipLaunchKernelGGL((spectral_step_kernel<8, false, true>), grd, blk, lds, s, p, a);
+        return hipGetLastError();
+    }
+    if (p.kx == 8) hipLaunchKernelGGL((spectral_step_kernel<4, true, false>), grd, blk, lds, s, p, a);
+    else if (p.kx < 8) hipLaunchKernelGGL((spectral_step_kernel<4, false, false>), grd, blk, lds, s, p, a);
+    else if (p.kx == 16) hipLaunchKernelGGL((spectral_step_kernel<8, true, false>), grd, blk, lds, s, p, a);
+    else hipLaunchKernelGGL((spectral_step_kernel<8, false, false>), grd, blk, lds, s, p, a);
     return hipGetLastError();
 }
 

@@ -496,6 +496,67 @@ module spdy_c
             type(c_ptr), intent(in) :: d_full(*)
             integer(c_int) :: rc
         end function
+        ! ranks inside one process (one host thread + one plan per GPU) and the complete level-sharded step
+        function spdy_comm_group_create(nranks, group) bind(C, name="spdy_comm_group_create") result(rc)
+            import :: c_int, c_ptr
+            integer(c_int), value :: nranks
+            type(c_ptr), intent(out) :: group
+            integer(c_int) :: rc
+        end function
+        function spdy_comm_group_destroy(group) bind(C, name="spdy_comm_group_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: group
+            integer(c_int) :: rc
+        end function
+        function spdy_comm_create_local(plan, group, rank, comm) bind(C, name="spdy_comm_create_local") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, group
+            integer(c_int), value :: rank
+            type(c_ptr), intent(out) :: comm
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_step_workspace(comm) bind(C, name="spdy_sharded_step_workspace") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_step_dev(comm, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, sdrag, j1, j2, dt, eps, wil, phi, tend_out) &
+                & bind(C, name="spdy_sharded_step_dev") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: comm, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, tend_out
+            real(c_double), value :: sdrag, dt, eps, wil
+            integer(c_int), value :: j1, j2
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_step_grid_dev(comm, vor, div, t, tr, ps, j2) bind(C, name="spdy_sharded_step_grid_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm, vor, div, t, tr, ps
+            integer(c_int), value :: j2
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_step_operands(comm, u, v, plain, lo, hi) bind(C, name="spdy_sharded_step_operands") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm
+            type(c_ptr), intent(out) :: u, v, plain
+            integer(c_int), intent(out) :: lo, hi
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_step_spectral_dev(comm, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, sdrag, j1, dt, eps, wil, phi, &
+                & tend_out) bind(C, name="spdy_sharded_step_spectral_dev") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: comm, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, tend_out
+            real(c_double), value :: sdrag, dt, eps, wil
+            integer(c_int), value :: j1
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_step_stacks(comm, grid_stack, grid_doubles, spec_stack, spec_doubles) &
+                & bind(C, name="spdy_sharded_step_stacks") result(rc)
+            import :: c_int, c_ptr, c_size_t
+            type(c_ptr), value :: comm
+            type(c_ptr), intent(out) :: grid_stack, spec_stack
+            integer(c_size_t), intent(out) :: grid_doubles, spec_doubles
+            integer(c_int) :: rc
+        end function
         function spdy_uvspec_to_grid_dev(plan, nb, d_vor, d_div, d_ug, d_vg, kcos) &
                 & bind(C, name="spdy_uvspec_to_grid_dev") result(rc)
             import :: c_int, c_ptr

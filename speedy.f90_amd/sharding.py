@@ -4,9 +4,12 @@ the GPU box, "gloo" in CPU tests).
 The per-time-step transform batch is indexed by b = (field, level) and every 2-D transform is
 independent, so the batch is partitioned contiguously -- rank r of R owns
 b in [r*B/R, (r+1)*B/R) -- with all tables replicated and NO data-path collective.  The only
-spectral-space step that couples levels is implicit_terms (implicit.f90:174-216): when tendencies
-are sharded by level, its inputs are completed with one all-gather of (divdt, tdt) level slabs
-(psdt is level-free and replicated).
+spectral-space step that couples levels on its own is implicit_terms (implicit.f90:174-216): its inputs
+are completed with one all-gather of (divdt, tdt) level slabs (sharded_implicit_terms).  A complete
+level-sharded time step has more level couplings (the grid-space tendencies' vertical sums,
+get_spectral_tendencies' dmean / sigma-dot, the hydrostatic integration): LevelComm.sharded_step_ is
+the device path for it (include/spdy.h: spdy_sharded_step_dev), sharded_step_host its field-by-field
+host mirror for the CPU tests.
 """
 import torch
 import torch.distributed as dist
@@ -51,14 +54,45 @@ def allgather_levels(local, kx):
     return torch.cat(parts, dim=0)
 
 
+class _DevArray:
+    """A plan-owned device buffer as something torch.as_tensor can wrap without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class LocalGroup:
+    """Ranks inside this process (include/spdy.h: spdy_comm_group_*): one host thread and one plan per rank, on one or on
+    several devices; collectives are peer copies between the ranks' streams, no RCCL.  How a single-process host drives
+    several GPUs -- and how the multi-rank paths run on a 1-GPU box."""
+
+    def __init__(self, lib, nranks):
+        import ctypes
+        from ._lib import check
+        self.lib, self.nranks, self.h = lib, nranks, ctypes.c_void_p()
+        check(lib.spdy_comm_group_create(nranks, ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            from ._lib import check
+            check(self.lib.spdy_comm_group_destroy(self.h))
+            self.h = None
+
+
 class LevelComm:
     """The C-ABI communicator (include/spdy.h: spdy_comm_*): direct RCCL collectives on the plan's stream, no torch
     ops, graph-capturable.  One per process/GPU; the RCCL unique id travels over the already initialised
-    torch.distributed group (any backend) -- a Fortran/MPI host would MPI_Bcast it instead."""
+    torch.distributed group (any backend) -- a Fortran/MPI host would MPI_Bcast it instead.
+    LevelComm(sp, group=LocalGroup, rank=r): rank r of an in-process group instead."""
 
-    def __init__(self, sp):
+    def __init__(self, sp, group=None, rank=None):
         import ctypes
         from ._lib import check
+        h = ctypes.c_void_p()
+        if group is not None:
+            check(sp.lib.spdy_comm_create_local(sp.h, group.h, rank, ctypes.byref(h)))
+            self.sp, self.h, self.rank, self.world, self.group = sp, h, rank, group.nranks, group
+            return
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
         ident = ctypes.create_string_buffer(128)
@@ -68,9 +102,8 @@ class LevelComm:
             box = [bytes(ident.raw)]
             dist.broadcast_object_list(box, src=0)
             ident = ctypes.create_string_buffer(box[0], 128)
-        h = ctypes.c_void_p()
         check(sp.lib.spdy_comm_create(sp.h, world, rank, ident, ctypes.byref(h)))
-        self.sp, self.h, self.rank, self.world = sp, h, rank, world
+        self.sp, self.h, self.rank, self.world, self.group = sp, h, rank, world, None
 
     def level_range(self, nlev):
         return shard_range(nlev, self.rank, self.world)
@@ -88,6 +121,54 @@ class LevelComm:
         self.sp._sync_stream()
         check(self.sp.lib.spdy_implicit_terms_sharded_dev(self.h, divdt_full.data_ptr(), tdt_full.data_ptr(), psdt.data_ptr()))
 
+    # ---- the complete level-sharded time step (spdy_sharded_step_*)
+    def sharded_step_workspace(self):
+        from ._lib import check
+        check(self.sp.lib.spdy_sharded_step_workspace(self.h))
+
+    def sharded_step_(self, vor, div, t, tr, ps, phis, tcorh, qcorh, sdrag, j1, j2, dt, eps, wil, phi, tend=None):
+        """One adiabatic step, transforms sharded by level; the prognostics ([2, kx, nx, mx] / [2, nx, mx]) are updated in
+        place on every rank; tend ([4 kx + 1, nx, mx], optional) receives vordt | divdt | tdt | trdt | psdt."""
+        from ._lib import check
+        self.sp._sync_stream()
+        check(self.sp.lib.spdy_sharded_step_dev(self.h, vor.data_ptr(), div.data_ptr(), t.data_ptr(), tr.data_ptr(), ps.data_ptr(),
+                                                phis.data_ptr(), tcorh.data_ptr(), qcorh.data_ptr(), sdrag, j1, j2, dt, eps, wil,
+                                                phi.data_ptr(), tend.data_ptr() if tend is not None else None))
+
+    def sharded_step_grid_(self, vor, div, t, tr, ps, j2):
+        from ._lib import check
+        self.sp._sync_stream()
+        check(self.sp.lib.spdy_sharded_step_grid_dev(self.h, vor.data_ptr(), div.data_ptr(), t.data_ptr(), tr.data_ptr(), ps.data_ptr(), j2))
+
+    def sharded_step_spectral_(self, vor, div, t, tr, ps, phis, tcorh, qcorh, sdrag, j1, dt, eps, wil, phi, tend=None):
+        from ._lib import check
+        self.sp._sync_stream()
+        check(self.sp.lib.spdy_sharded_step_spectral_dev(self.h, vor.data_ptr(), div.data_ptr(), t.data_ptr(), tr.data_ptr(), ps.data_ptr(),
+                                                         phis.data_ptr(), tcorh.data_ptr(), qcorh.data_ptr(), sdrag, j1, dt, eps, wil,
+                                                         phi.data_ptr(), tend.data_ptr() if tend is not None else None))
+
+    def sharded_step_operands(self):
+        """(U, V, PL, lo, hi): this rank's direct-batch operands as torch views of the communicator's workspace -- where a host
+        with physics adds its grid-space tendencies between the two halves of the step."""
+        import ctypes
+        from ._lib import check
+        u, v, pl, lo, hi = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        check(self.sp.lib.spdy_sharded_step_operands(self.h, ctypes.byref(u), ctypes.byref(v), ctypes.byref(pl), ctypes.byref(lo), ctypes.byref(hi)))
+        nl, sp = hi.value - lo.value, self.sp
+        dev = "cuda:%d" % sp.device
+        mk = lambda ptr, n: torch.as_tensor(_DevArray(ptr.value, (n, sp.il, sp.ix), "<f8"), device=dev)
+        return mk(u, 3 * nl), mk(v, 3 * nl), mk(pl, 3 * nl + 1), lo.value, hi.value
+
+    def sharded_step_stacks(self):
+        """The two exchanged level-block stacks (grid: 6 kx grids; spectral: 9 kx + nranks spectra) as flat float64 views."""
+        import ctypes
+        from ._lib import check
+        g, gn, t, tn = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_void_p(), ctypes.c_size_t()
+        check(self.sp.lib.spdy_sharded_step_stacks(self.h, ctypes.byref(g), ctypes.byref(gn), ctypes.byref(t), ctypes.byref(tn)))
+        dev = "cuda:%d" % self.sp.device
+        return (torch.as_tensor(_DevArray(g.value, (gn.value,), "<f8"), device=dev),
+                torch.as_tensor(_DevArray(t.value, (tn.value,), "<f8"), device=dev))
+
     def close(self):
         if self.h:
             self.sp.lib.spdy_comm_destroy(self.h)
@@ -98,6 +179,85 @@ class LevelComm:
             self.close()
         except Exception:
             pass
+
+
+# ---- the level-block layout of the sharded step (csrc/spdy_kernels.hpp: LevelShard), mirrored for the host ---------------
+def level_owner(k, kx, world):
+    """Rank that owns level k when rank r owns [kx r / world, kx (r + 1) / world)."""
+    return (world * (k + 1) - 1) // kx
+
+
+def block_slab(f, k, kx, world, nfields, nextra=0):
+    """Slab index of field f, level k in a level-block stack of `nfields` fields x kx levels (+ `nextra` level-free slabs per
+    rank behind its block): block r starts at nfields * lo_r + nextra * r and is the rank's own [nfields][nl_r] operand."""
+    r = level_owner(k, kx, world)
+    lo, hi = shard_range(kx, r, world)
+    return nfields * lo + nextra * r + f * (hi - lo) + (k - lo)
+
+
+def allgather_blocks(local, sizes):
+    """local: this rank's block (first axis = slabs, sizes[rank] of them); returns the concatenation of all ranks' blocks."""
+    world = dist.get_world_size()
+    nmax = max(sizes)
+    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype)
+    if local.is_complex():
+        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(pad))
+    else:
+        dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * nmax: r * nmax + sizes[r]] for r in range(world)], dim=0)
+
+
+def sharded_step_host(ex, st, rank, world, j1, j2, dt, eps, wil, sdrag, gather=allgather_blocks):
+    """The data flow of spdy_sharded_step_dev on the host, field by field, with `ex` as the executor of the single pieces (the
+    reference's procedures: uvspec, spec_to_grid, grad, grid_tendencies, vdspec, grid_to_spec, tendency_combine,
+    spectral_tendencies, implicit_terms, hdiff_step, step_field) -- what the CPU tests run with their host executor plugged in, over
+    gloo.  Rank `rank` transforms ITS levels only; the level-block stacks G (6 kx grids) and T (9 kx + world spectra) are each
+    completed by one gather of one contiguous block per rank, exactly as in the C implementation; the column procedures then
+    run on full columns.  st: {vor, div, t, tr: [2, kx, nx, mx]; ps: [2, nx, mx]; phis, tcorh, qcorh: [nx, mx]} complex NumPy
+    arrays, the full state on every rank.  Returns (new state, final tendencies dict)."""
+    import numpy as np
+    kx = st["vor"].shape[1]
+    lo, hi = shard_range(kx, rank, world)
+    nl, lv = hi - lo, j2 - 1
+    sizes = shard_sizes(kx, world)
+    # 1: inverse batch of the rank's levels -> its block [ug | vg | vorg | divg | tg | trg] (nl each); grad(ps) everywhere
+    blk = []
+    uv = [ex.uvspec(st["vor"][lv, k], st["div"][lv, k]) for k in range(lo, hi)]
+    blk += [ex.spec_to_grid(u, 2) for u, _ in uv] + [ex.spec_to_grid(v, 2) for _, v in uv]
+    for n in ("vor", "div", "t", "tr"):
+        blk += [ex.spec_to_grid(st[n][lv, k], 1) for k in range(lo, hi)]
+    dx, dy = ex.grad(st["ps"][lv])
+    px, py = ex.spec_to_grid(dx, 2), ex.spec_to_grid(dy, 2)
+    # 2: one gather of the grid stack
+    G = gather(torch.from_numpy(np.stack(blk)), [6 * n for n in sizes]).numpy()
+    col = lambda f: np.stack([G[block_slab(f, k, kx, world, 6)] for k in range(kx)])
+    ug, vg, vorg, divg, tg, trg = (col(f) for f in range(6))
+    # 3: grid tendencies on full columns; this rank keeps its own levels' operands
+    U, V, PL = ex.grid_tendencies(ug, vg, tg, vorg, divg, trg, px, py)
+    own = [g * kx + k for g in range(3) for k in range(lo, hi)]
+    Ul, Vl, PLl = U[own], V[own], np.concatenate([PL[own], PL[3 * kx:]])
+    # 4: direct batch of the rank's levels (+ the level-free ps tendency) -> its block [pvor | pdiv | pspec (3 nl each)] | psdt
+    vd = [ex.vdspec(Ul[i], Vl[i], 2) for i in range(3 * nl)]
+    blk = [x[0] for x in vd] + [x[1] for x in vd] + [ex.grid_to_spec(PLl[i]) for i in range(3 * nl + 1)]
+    # 5: one gather of the spectral stack
+    T = gather(torch.from_numpy(np.stack(blk)), [9 * n + 1 for n in sizes]).numpy()
+    stack = lambda f0: np.stack([T[block_slab(f0 + g, k, kx, world, 9, 1)] for g in range(3) for k in range(kx)])
+    pvor, pdiv = stack(0), stack(3)
+    pspec = np.concatenate([stack(6), T[9 * sizes[0]][None]])                    # psdt: block 0's copy
+    # 6: the spectral side on full columns (time level 1 feeds the tendencies and the diffusion)
+    pdiv, pspec = ex.tendency_combine(pdiv, pspec)
+    vordt, divdt, tdt, trdt, psdt = pvor[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[3 * kx]
+    divdt, tdt, psdt, phi = ex.spectral_tendencies(st["div"][0], st["t"][0], st["ps"][0], st["phis"], divdt, tdt, psdt)
+    divdt, tdt, psdt = ex.implicit_terms(divdt, tdt, psdt)
+    vordt, divdt, tdt, trdt = ex.hdiff_step(st["vor"][0], st["div"][0], st["t"][0], st["tr"][0], st["tcorh"], st["qcorh"], sdrag,
+                                            vordt, divdt, tdt, trdt)
+    new, fin = dict(st), {"phi": phi, "U": Ul, "V": Vl, "PL": PLl}
+    new["ps"], fin["psdt"] = ex.step_field(j1, dt, eps, wil, st["ps"], psdt)
+    for n, d in (("vor", vordt), ("div", divdt), ("t", tdt), ("tr", trdt)):
+        new[n], fin[n + "dt"] = ex.step_field(j1, dt, eps, wil, st[n], d)
+    return new, fin
 
 
 def sharded_implicit_terms(sp, divdt_local, tdt_local, psdt, comm=None):

@@ -1,0 +1,300 @@
+"""GPU: the COMPLETE level-sharded adiabatic time step (BASELINE.json config 3; include/spdy.h: spdy_sharded_step_dev).
+
+Every rank holds the full prognostic state, transforms only its own levels and receives every other level of the two
+intermediate stacks (gridded prognostics, spectral tendencies) through ONE all-gather each; the two column kernels
+(get_grid_point_tendencies; tendency combination + get_spectral_tendencies + implicit_terms + diffusion + leapfrog) then run on
+full columns.  Reference lines that couple levels: tendencies.f90:109-197, :256-285, geopotential.f90:33-57,
+implicit.f90:174-216.
+
+What runs where:
+  * ranks INSIDE this process (spdy_comm_create_local: one thread + one plan per rank, all on device 0) -- real multi-rank
+    runs of the very entry point an RCCL rank calls, on a 1-GPU box: world 1, 2 (equal blocks), 3 (ragged blocks), T30 L8,
+    T30 L5 and T63 L16 (the raw-pairs route of the T63 direct batch).  The exchanged stacks are NaN-poisoned between steps:
+    a level that a rank neither computed nor received would poison its result.
+  * RCCL at world size 1 with SPDY_COMM_FORCE (the collectives are really issued, both routes), eager and captured into a graph.
+  * RCCL ranks in separate processes (world 2 and 3) where the box has the GPUs (skipped otherwise).
+Checked against the oracle's call-by-call step (1e-12) AND against the unsharded device step (bit for bit: the transforms are
+position-independent and the column kernels evaluate the same expressions)."""
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import TOL, VARIANTS
+from dynstep import ROB, SDRAG, WIL, oracle_dynamics_step, state, wave_relerr
+
+pytestmark = pytest.mark.gpu
+DT = 2400.0
+PROGS = ("vor", "div", "t", "tr", "ps")
+
+
+def make_plan(tag, device=0):
+    import speedy_f90_amd as s
+    trunc, ix, iy, kx = VARIANTS[tag]
+    sp = s.Spectral((trunc, ix, iy), kx=kx, max_batch=4 * kx + 4, device=device)
+    if tag in synth.SIGMA_SETS:
+        sp.set_sigma(synth.SIGMA_SETS[tag])
+    sp.initialize_implicit(DT)
+    return sp
+
+
+def unsharded_device_steps(sp, st, nsteps):
+    """The three-call device step (tests/test_gpu_step.py) on one plan: prognostics, tendencies and direct-batch operands."""
+    import torch
+    kx, nx, mx, il, ix = sp.kx, sp.nx, sp.mx, sp.il, sp.ix
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    D = {n: dev(st[n]) for n in st}
+    P = 3 * kx
+    c128 = lambda *shape: torch.zeros(shape, dtype=torch.complex128, device="cuda")
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device="cuda")
+    ug, vg, plain_g, px, py = f64(kx, il, ix), f64(kx, il, ix), f64(4 * kx, il, ix), f64(1, il, ix), f64(1, il, ix)
+    U, V, PL = f64(P, il, ix), f64(P, il, ix), f64(P + 1, il, ix)
+    pvor, pdiv, pspec, phi = c128(P, nx, mx), c128(P, nx, mx), c128(P + 1, nx, mx), c128(kx, nx, mx)
+    for _ in range(nsteps):
+        sp.inverse_batch_segs_dev(D["vor"][1], D["div"][1], ug, vg, [D[n][1] for n in ("vor", "div", "t", "tr")], plain_g, D["ps"][1:2], px, py,
+                                  kcos_pairs=2, kcos=1)
+        sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
+        sp.direct_batch_spectral_step_dev(U, V, PL, pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"],
+                                          D["qcorh"], SDRAG, 2, DT, ROB, WIL, phi, kcos=2)
+    torch.cuda.synchronize()
+    out = {n: D[n].cpu().numpy() for n in PROGS}
+    out["phi"] = phi.cpu().numpy()
+    out["tend"] = np.concatenate([pvor[:kx].cpu().numpy(), pdiv.cpu().numpy(), pspec[P:].cpu().numpy()])   # vordt | divdt | tdt | trdt | psdt
+    out["U"], out["V"], out["PL"] = U.cpu().numpy(), V.cpu().numpy(), PL.cpu().numpy()
+    return out
+
+
+def _rank_thread(rank, group, tag, st, nsteps, results, errors):
+    import torch
+    import speedy_f90_amd as s
+    try:
+        sp = make_plan(tag)
+        sp.use_own_stream()
+        comm = s.sharding.LevelComm(sp, group=group, rank=rank)
+        comm.sharded_step_workspace()
+        kx, nx, mx = sp.kx, sp.nx, sp.mx
+        D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
+        phi = torch.zeros((kx, nx, mx), dtype=torch.complex128, device="cuda")
+        tend = torch.zeros((4 * kx + 1, nx, mx), dtype=torch.complex128, device="cuda")
+        G, T = comm.sharded_step_stacks()
+        torch.cuda.synchronize()
+        for step in range(nsteps):
+            G.fill_(float("nan")); T.fill_(float("nan"))          # whatever a rank does not compute must ARRIVE, or it poisons the step
+            torch.cuda.synchronize()
+            if step == 0:                                         # the one call ...
+                comm.sharded_step_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, 2, DT, ROB, WIL,
+                                   phi, tend)
+            else:                                                 # ... and its two halves (the physics hook sits between them)
+                comm.sharded_step_grid_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], 2)
+                comm.sharded_step_spectral_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, DT, ROB,
+                                            WIL, phi, tend)
+            sp.synchronize()
+        U, V, PL, lo, hi = comm.sharded_step_operands()
+        out = {n: D[n].cpu().numpy() for n in PROGS}
+        out.update(phi=phi.cpu().numpy(), tend=tend.cpu().numpy(), U=U.cpu().numpy(), V=V.cpu().numpy(), PL=PL.cpu().numpy(), lo=lo, hi=hi)
+        results[rank] = out
+        comm.close(); sp.close()
+    except Exception as e:          # a missing rank would leave the others waiting for the group's timeout
+        errors[rank] = e
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+def test_sharded_step_in_process_ranks(tag, world, oracle_factory, monkeypatch):
+    import speedy_f90_amd as s
+    monkeypatch.setenv("SPDY_COMM_TIMEOUT_S", "60")
+    kx = VARIANTS[tag][3]
+    o = oracle_factory(tag)
+    o.tail_init(DT)
+    sp0 = make_plan(tag)
+    st = state(sp0, 8000)
+    nsteps = 2
+    whole = unsharded_device_steps(sp0, st, nsteps)
+    group = s.sharding.LocalGroup(sp0.lib, world)
+    results, errors = {}, {}
+    threads = [threading.Thread(target=_rank_thread, args=(r, group, tag, st, nsteps, results, errors)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    assert sorted(results) == list(range(world))
+    group.close(); sp0.close()
+    ref = st
+    for _ in range(nsteps):
+        ref, out = oracle_dynamics_step(o, ref, 2, DT, ROB)
+    ref_tend = np.concatenate([out["vordt"], out["divdt"], out["tdt"], out["trdt"], out["psdt"][None]])
+    worst = 0.0
+    for r in range(world):
+        got = results[r]
+        assert (got["lo"], got["hi"]) == s.sharding.shard_range(kx, r, world)
+        own = [g * kx + k for g in range(3) for k in range(got["lo"], got["hi"])]
+        # vs the oracle's call-by-call step: the north star's bar
+        for n in PROGS:
+            worst = max(worst, synth.relerr(got[n], ref[n]), wave_relerr(got[n], ref[n]))
+        worst = max(worst, wave_relerr(got["phi"], out["phi"]))
+        for a in range(4):
+            worst = max(worst, wave_relerr(got["tend"][a * kx:(a + 1) * kx], ref_tend[a * kx:(a + 1) * kx]))
+        worst = max(worst, synth.relerr(got["tend"][4 * kx], ref_tend[4 * kx]))
+        worst = max(worst, synth.relerr(got["U"], out["U"][own]), synth.relerr(got["V"], out["V"][own]),
+                    synth.relerr(got["PL"], np.concatenate([out["PL"][own], out["PL"][3 * kx:]])))
+        # vs the unsharded device step: same bits, whatever the rank count
+        for n in PROGS + ("phi", "tend"):
+            assert np.array_equal(got[n], whole[n]), (tag, world, r, n, synth.relerr(got[n], whole[n]))
+        assert np.array_equal(got["U"], whole["U"][own]) and np.array_equal(got["V"], whole["V"][own])
+        assert np.array_equal(got["PL"], np.concatenate([whole["PL"][own], whole["PL"][3 * kx:]]))
+    print("\n[sharded step %s, %d in-process ranks] worst relative error vs the oracle %.1e; bits equal to the unsharded device step"
+          % (tag, world, worst))
+    assert worst <= TOL, (tag, world, worst)
+
+
+def test_in_process_group_errors():
+    """A rank that never shows up breaks the group after the timeout (SPDY_ERR_COMM) instead of hanging its peers; collectives of
+    an in-process communicator are refused inside a graph capture; a group cannot be destroyed under its communicators."""
+    import torch
+    import speedy_f90_amd as s
+    from speedy_f90_amd._lib import SpdyError
+    os.environ["SPDY_COMM_TIMEOUT_S"] = "2"
+    try:
+        sp = make_plan("t30")
+        sp.use_own_stream()
+        group = s.sharding.LocalGroup(sp.lib, 2)
+        comm = s.sharding.LevelComm(sp, group=group, rank=0)
+        with pytest.raises(SpdyError):
+            group.close()
+        full = torch.zeros((8, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        with pytest.raises(SpdyError, match="ranks arrived"):
+            comm.allgather_levels_(full)
+        with pytest.raises(SpdyError):                 # the group stays broken
+            comm.allgather_levels_(full)
+        comm.close(); group.close()
+        group = s.sharding.LocalGroup(sp.lib, 1)
+        comm = s.sharding.LevelComm(sp, group=group, rank=0)
+        with pytest.raises(SpdyError, match="capture"):
+            with sp.graph_capture():
+                comm.allgather_levels_(full)
+        comm.close(); group.close(); sp.close()
+    finally:
+        os.environ.pop("SPDY_COMM_TIMEOUT_S", None)
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["t30", "t63k16"])
+def test_sharded_step_rccl_graph_world1(tag, nccl_world1, oracle_factory, monkeypatch):
+    """The sharded step over RCCL as ONE captured graph per rank, at world size 1 with SPDY_COMM_FORCE: 1 = the in-place
+    ncclAllGather route, 2 = the per-rank ncclBroadcast route of ragged blocks -- both exchanges really issued as graph nodes
+    between the transform launches and the column kernels.  Two replays against the oracle and the unsharded device step."""
+    import torch
+    import speedy_f90_amd as s
+    kx = VARIANTS[tag][3]
+    o = oracle_factory(tag)
+    o.tail_init(DT)
+    sp0 = make_plan(tag)
+    st = state(sp0, 8000)
+    whole = unsharded_device_steps(sp0, st, 2)
+    sp0.close()
+    ref = st
+    for _ in range(2):
+        ref, out = oracle_dynamics_step(o, ref, 2, DT, ROB)
+    for force in ("1", "2"):
+        monkeypatch.setenv("SPDY_COMM_FORCE", force)
+        sp = make_plan(tag)
+        sp.use_own_stream()
+        comm = s.sharding.LevelComm(sp)
+        comm.sharded_step_workspace()
+        D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
+        phi = torch.zeros((kx, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+        tend = torch.zeros((4 * kx + 1, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        with sp.graph_capture() as g:
+            comm.sharded_step_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, 2, DT, ROB, WIL, phi, tend)
+        for _ in range(2):
+            g.launch()
+        sp.synchronize()
+        for n in PROGS:
+            got = D[n].cpu().numpy()
+            assert max(synth.relerr(got, ref[n]), wave_relerr(got, ref[n])) <= TOL, (force, n)
+            assert np.array_equal(got, whole[n]), (force, n)
+        assert np.array_equal(tend.cpu().numpy(), whole["tend"]) and np.array_equal(phi.cpu().numpy(), whole["phi"])
+        g.close(); comm.close(); sp.close()
+
+
+def _rccl_rank(rank, world, port, tag, q):
+    import torch
+    import torch.distributed as dist
+    import speedy_f90_amd as s
+    from oracle.pyoracle import Oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        kx = VARIANTS[tag][3]
+        o = Oracle(*VARIANTS[tag])
+        if tag in synth.SIGMA_SETS:
+            o.set_sigma(synth.SIGMA_SETS[tag])
+        o.tail_init(DT)
+        sp = make_plan(tag, device=rank)
+        sp.use_own_stream()
+        comm = s.sharding.LevelComm(sp)
+        comm.sharded_step_workspace()
+        st = state(sp, 8000)
+        D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
+        phi = torch.zeros((kx, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+        G, T = comm.sharded_step_stacks()
+        G.fill_(float("nan")); T.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with sp.graph_capture() as g:
+            comm.sharded_step_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, 2, DT, ROB, WIL, phi)
+        ref = st
+        for _ in range(2):
+            g.launch()
+            ref, out = oracle_dynamics_step(o, ref, 2, DT, ROB)
+        sp.synchronize()
+        err = max(max(synth.relerr(D[n].cpu().numpy(), ref[n]), wave_relerr(D[n].cpu().numpy(), ref[n])) for n in PROGS)
+        g.close(); comm.close(); sp.close()
+        q.put((rank, err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tag", [(2, "t30"), (3, "t30"), (2, "t63k16")])
+def test_sharded_step_rccl_ranks(world, tag):
+    """BASELINE config 3 on real RCCL ranks (one process per GPU): every rank captures the complete sharded step -- its two
+    all-gathers included -- into a graph, replays it twice from NaN-poisoned exchange stacks and must hold the oracle's
+    prognostics.  world 3 with 8 levels: ragged blocks -> grouped ncclBroadcast.  Skipped on boxes with fewer GPUs."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, tag, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+        assert pr.exitcode == 0
+    got = dict(q.get(timeout=10) for _ in range(world))
+    assert sorted(got) == list(range(world)) and max(got.values()) <= TOL, got

@@ -76,6 +76,76 @@ def test_two_rank_sharding(world, kx, tmp_path):
         assert np.array_equal(np.load(tmp_path / ("imp_%d.npy" % r)), chunks[-1])
 
 
+def _step_worker(rank, world, port, kx, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import speedy_f90_amd as s
+    from oracle.pyoracle import Oracle
+    from dynstep import ROB, SDRAG, WIL, state
+    o = Oracle(30, 96, 24, kx)
+    o.tail_init(2400.0)
+    st = state(o, 8000)                       # the full prognostic state on every rank (the tail is replicated) ...
+    for step in range(2):                     # ... of which a rank only ever TRANSFORMS its own levels
+        st, fin = s.sharding.sharded_step_host(o, st, rank, world, 2, 2, 2400.0, ROB, WIL, SDRAG)
+    np.savez(os.path.join(outdir, "step_%d.npz" % rank), **{n: st[n] for n in ("vor", "div", "t", "tr", "ps")},
+             **{n: fin[n] for n in ("vordt", "divdt", "tdt", "trdt", "psdt", "phi", "U", "V", "PL")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kx", [(2, 8), (3, 8)])
+def test_multi_rank_sharded_step(world, kx, tmp_path):
+    """The COMPLETE level-sharded adiabatic step (speedy_f90_amd.sharding.sharded_step_host: the data flow of
+    spdy_sharded_step_dev with the oracle as the executor of the single procedures) over gloo: each rank transforms only its own
+    levels; the two level-block stacks are completed by one gather each; get_grid_point_tendencies, get_spectral_tendencies,
+    implicit_terms, the diffusion and the leapfrog run on full columns.  After two chained steps every rank must hold the
+    UNSHARDED oracle step's prognostics and tendencies bit for bit -- equal (world 2) and ragged (world 3, 8 levels) blocks.
+    This is the test that catches a level coupling left out of the exchange (round 3: psdt / get_spectral_tendencies)."""
+    port = _free_port()
+    mp.spawn(_step_worker, args=(world, port, kx, str(tmp_path)), nprocs=world, join=True)
+    import speedy_f90_amd as s
+    from oracle.pyoracle import Oracle
+    from dynstep import ROB, SDRAG, WIL, oracle_dynamics_step, state
+    o = Oracle(30, 96, 24, kx)
+    o.tail_init(2400.0)
+    ref = state(o, 8000)
+    for step in range(2):
+        ref, out = oracle_dynamics_step(o, ref, 2, 2400.0, ROB)
+    for r in range(world):
+        z = np.load(tmp_path / ("step_%d.npz" % r))
+        for n in ("vor", "div", "t", "tr", "ps"):
+            assert np.array_equal(z[n], ref[n]), (r, n)
+        for n in ("vordt", "divdt", "tdt", "trdt", "psdt", "phi"):
+            assert np.array_equal(z[n], out[n]), (r, n)
+        lo, hi = s.sharding.shard_range(kx, r, world)
+        own = [g * kx + k for g in range(3) for k in range(lo, hi)]
+        assert np.array_equal(z["U"], out["U"][own]) and np.array_equal(z["V"], out["V"][own])
+        assert np.array_equal(z["PL"], np.concatenate([out["PL"][own], out["PL"][3 * kx:]]))
+
+
+def test_level_block_layout():
+    """The level-block stacks of the sharded step (csrc/spdy_kernels.hpp: LevelShard; mirrored by sharding.block_slab): every
+    (field, level) -- and every rank's level-free extra slab -- has exactly one slab, a rank's slabs are contiguous, and the
+    owner formula the kernels use agrees with the block partition."""
+    import speedy_f90_amd as s
+    sh = s.sharding
+    for kx in (5, 7, 8, 16):
+        for w in range(1, kx + 1):
+            for k in range(kx):
+                lo, hi = sh.shard_range(kx, sh.level_owner(k, kx, w), w)
+                assert lo <= k < hi
+            for F, X in ((6, 0), (9, 1)):
+                seen = {}
+                for f in range(F):
+                    for k in range(kx):
+                        seen[sh.block_slab(f, k, kx, w, F, X)] = sh.level_owner(k, kx, w)
+                for r in range(w):
+                    lo, hi = sh.shard_range(kx, r, w)
+                    mine = sorted(i for i, o in seen.items() if o == r)
+                    assert mine == list(range(F * lo + X * r, F * hi + X * r)), (kx, w, F, r)
+                assert len(seen) == F * kx
+
+
 def test_shard_ranges_partition():
     import speedy_f90_amd as s
     for n in (0, 1, 7, 8, 48, 73, 91, 6144):
