@@ -429,16 +429,17 @@ class Watchdog:
 
 
 def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
-    """All ranks.  What a level-sharded model step adds to the transform batch (BASELINE config 3: T30 L8,
-    fields x levels over the ranks, RCCL all-gather for the cross-level implicit solve), through the C ABI:
+    """All ranks.  BASELINE config 3 (T30 L8, fields x levels over the ranks, RCCL all-gather over xGMI) through the C ABI:
       rccl_ranks          ranks of the communicator spdy_comm_create built (direct RCCL on the plan's stream)
       allgather_levels_us one in-place all-gather of the (divdt, tdt) level blocks, eager calls
-      sharded_step        ONE captured graph per rank: this rank's share of a step's transforms (levels [lo, hi): uvspec
-                          pairs + t, tr -> grid; 3 vdspec pairs + 3 plain fields per level -> spectra), its divdt/tdt level
-                          blocks placed in the full stacks, spdy_implicit_terms_sharded_dev (gather + solve on every
-                          rank) -- and the same graph with the local solve only ("without gather")
-    The grid-space tendencies between the two batches couple the levels of a column (tendencies.f90:109-197) and would
-    need a second, grid-space exchange in a level-sharded full model: not part of this path, left out of the graph."""
+      sharded_step        the COMPLETE level-sharded adiabatic step (include/spdy.h: spdy_sharded_step_dev) as ONE captured graph
+                          per rank: inverse batch of the rank's levels, all-gather of the gridded prognostics, grid tendencies
+                          on full columns, direct batch of the rank's levels, all-gather of the spectral tendencies, the
+                          one-launch spectral step on full columns -- every level coupling of the reference's step is inside
+                          (tendencies.f90:109-197, :256-285, geopotential.f90:33-57, implicit.f90:174-216).  Timed as graph
+                          replays, max over ranks; `us_without_exchanges` is the same graph from a communicator created under
+                          SPDY_COMM_DRY=1 (its collectives return at once: timing only); `us_unsharded` the three-call
+                          unsharded step of one GPU, the same state, for the strong-scaling ratio."""
     dist = torch.distributed
     out = {}
     kx = sp.kx
@@ -451,7 +452,6 @@ def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
     c128 = lambda *sh: torch.zeros(sh, dtype=torch.complex128, device=dev)
     f64 = lambda *sh: torch.zeros(sh, dtype=torch.float64, device=dev)
     full = [c128(kx, sp.nx, sp.mx) for _ in range(2)]
-    psdt = c128(sp.nx, sp.mx)
     mx_ = lambda x: s.sharding.max_over_ranks(x, dev)
 
     def timed(fn, reps=50, warm=5):
@@ -468,40 +468,59 @@ def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
 
     out["allgather_levels_us"] = timed(lambda: comm.allgather_levels_(*full))
     out["allgather_bytes_per_rank"] = 2 * nl * sp.nx * sp.mx * 16
-    # ---- the level-sharded step as one graph per rank
-    spec = lambda n, first, sc: torch.from_numpy(synth.spectra(max(n, 1), sp.trunc, first=first) * sc).to(dev)[:n]
-    vor, div, plain = spec(nl, 1 + lo, 1e-5), spec(nl, 100 + lo, 1e-6), spec(2 * nl, 200 + 2 * lo, 1.0)
-    ngrad = 1 if rank == 0 else 0                                   # grad(ps) -> grid and the ps tendency live on rank 0
-    psi = spec(1, 400, 0.01)
-    ug, vg, pg, px, py = f64(nl, sp.il, sp.ix), f64(nl, sp.il, sp.ix), f64(2 * nl, sp.il, sp.ix), f64(1, sp.il, sp.ix), f64(1, sp.il, sp.ix)
-    P = 3 * nl
-    U, V, PL = torch.randn(P, sp.il, sp.ix, dtype=torch.float64, device=dev), torch.randn(P, sp.il, sp.ix, dtype=torch.float64, device=dev), \
-        torch.randn(P + ngrad, sp.il, sp.ix, dtype=torch.float64, device=dev)
-    pvor, pdiv, pspec = c128(P, sp.nx, sp.mx), c128(P, sp.nx, sp.mx), c128(P + ngrad, sp.nx, sp.mx)
-    side = torch.cuda.Stream(device=dev)
-    times = {}
-    with torch.cuda.stream(side):
-        sp.use_torch_stream()                       # the plan runs on `side`; torch's copies below are captured with it
-        torch.cuda.synchronize()
-        for tag, gather in (("with_gather", True), ("without_gather", False)):
-            with sp.graph_capture() as g:
-                if nl:
-                    sp.inverse_batch_grad_dev(vor, div, ug, vg, plain, pg, psi[:ngrad], px[:ngrad], py[:ngrad], kcos_pairs=2, kcos=1)
-                    sp.direct_batch_dev(U, V, pvor, pdiv, PL, pspec, kcos=2)
-                    full[0][lo:hi].copy_(pdiv[:nl])                 # divdt, tdt level blocks into the full stacks
-                    full[1][lo:hi].copy_(pdiv[nl:2 * nl])
-                if gather:
-                    comm.implicit_terms_sharded_(full[0], full[1], psdt)
-                else:
-                    sp.implicit_terms_dev(full[0], full[1], psdt)
-            times[tag] = timed(g.launch)
-            g.close()
-        side.synchronize()
+    # ---- the complete level-sharded step as one graph per rank
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dynstep import ROB, SDRAG, WIL, state
+    st = state(sp, 8000)
+    for n in ("vor", "div", "t", "tr", "ps"):          # (timing only: small-amplitude waves, so that a few dozen replays stay finite)
+        mean = st[n][..., :1, :1].copy()
+        st[n] *= 1e-3
+        st[n][..., :1, :1] = mean
     sp.use_own_stream()
-    out["sharded_step"] = {"us_with_gather": times["with_gather"], "us_without_gather": times["without_gather"],
-                           "transforms_per_rank": (6 * nl + 2 * ngrad, 9 * nl + ngrad), "launches_in_graph": 5,
-                           "note": "per-rank graph: inverse batch, direct batch, 2 level-block copies, (RCCL all-gather +) "
-                                   "implicit_terms; max over ranks; grid-space column coupling not included"}
+
+    def fresh():
+        D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).to(dev) for n in st}
+        D["phi"] = c128(kx, sp.nx, sp.mx)
+        return D
+
+    def replay_us(c):
+        D = fresh()
+        c.sharded_step_workspace()
+        torch.cuda.synchronize()
+        with sp.graph_capture() as g:
+            c.sharded_step_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, 2, 2400.0, ROB, WIL, D["phi"])
+        us = timed(g.launch, reps=40, warm=3)          # (a few dozen leapfrog steps of a seeded state: stays finite)
+        g.close()
+        return us, D
+    us_with, D = replay_us(comm)
+    finite = bool(torch.isfinite(torch.view_as_real(D["vor"])).all().item())
+    os.environ["SPDY_COMM_DRY"] = "1"
+    dry = s.sharding.LevelComm(sp)
+    os.environ.pop("SPDY_COMM_DRY")
+    us_dry, _ = replay_us(dry)
+    dry.close()
+    # the unsharded step of one GPU on the same state (every rank runs it; identical work)
+    D = fresh()
+    P = 3 * kx
+    ug, vg, pg, px, py = f64(kx, sp.il, sp.ix), f64(kx, sp.il, sp.ix), f64(4 * kx, sp.il, sp.ix), f64(1, sp.il, sp.ix), f64(1, sp.il, sp.ix)
+    U, V, PL = f64(P, sp.il, sp.ix), f64(P, sp.il, sp.ix), f64(P + 1, sp.il, sp.ix)
+    pvor, pdiv, pspec = c128(P, sp.nx, sp.mx), c128(P, sp.nx, sp.mx), c128(P + 1, sp.nx, sp.mx)
+    torch.cuda.synchronize()
+    with sp.graph_capture() as g:
+        sp.inverse_batch_segs_dev(D["vor"][1], D["div"][1], ug, vg, [D[n][1] for n in ("vor", "div", "t", "tr")], pg, D["ps"][1:2], px, py,
+                                  kcos_pairs=2, kcos=1)
+        sp.grid_tendencies_dev(ug, vg, pg[2 * kx:3 * kx], pg[:kx], pg[kx:2 * kx], pg[3 * kx:], px, py, U, V, PL)
+        sp.direct_batch_spectral_step_dev(U, V, PL, pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"],
+                                          D["qcorh"], SDRAG, 2, 2400.0, ROB, WIL, D["phi"], kcos=2)
+    us_whole = timed(g.launch, reps=40, warm=3)
+    g.close()
+    gs, ss = sp.il * sp.ix * 8, sp.nx * sp.mx * 16
+    out["sharded_step"] = {"us_with_exchanges": us_with, "us_without_exchanges": us_dry, "us_unsharded": us_whole,
+                           "state_finite_after_replays": finite,
+                           "transforms_per_rank": (6 * nl + 2, 9 * nl + 1), "exchange_bytes_per_rank": (6 * nl * gs, (9 * nl + 1) * ss),
+                           "exchange_bytes_total": (6 * kx * gs, (9 * kx + world) * ss), "launches_in_graph": "4 kernels + 2 all-gathers",
+                           "note": "complete adiabatic step, transforms sharded by level, both level exchanges inside the graph; "
+                                   "max over ranks of graph-replay time"}
     comm.close()
     return out
 

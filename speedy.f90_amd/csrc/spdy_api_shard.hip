@@ -80,6 +80,8 @@ struct spdy_comm {
     int nranks = 1, rank = 0;
     int force = 0;                    // $SPDY_COMM_FORCE (debug): 1 = issue the RCCL collectives even with one rank,
                                       // 2 = ... and take the ragged (per-rank broadcast) route for equal blocks too
+    int dry = 0;                      // $SPDY_COMM_DRY=1 (measurement): collectives return at once -- what a sharded step costs
+                                      // WITHOUT its exchanges (results are then wrong wherever another rank's block is read)
     // workspace of the level-sharded step (spdy_sharded_step_workspace; plan-owned device memory)
     double *G = nullptr;              // level-block stack of the gridded prognostics: 6 kx grids
     double *px = nullptr, *py = nullptr;
@@ -164,7 +166,7 @@ int group_barrier(spdy_comm_group *g)
 int allgather_blocks(spdy_comm *c, int narr, double *const *d, const size_t *off, const size_t *cnt)
 {
     spdy_plan *p = c->plan;
-    if (narr == 0) return SPDY_OK;
+    if (narr == 0 || c->dry) return SPDY_OK;
     if (c->grp) {
         spdy_comm_group *g = c->grp;
         NOT_CAPTURING(p, "a collective of an in-process communicator (peer copies ordered by events of other ranks' streams)");
@@ -231,6 +233,7 @@ int spdy_comm_create(spdy_plan *p, int nranks, int rank, const char *id, spdy_co
     spdy_comm *c = new spdy_comm;
     c->plan = p; c->nranks = nranks; c->rank = rank;
     if (const char *env = getenv("SPDY_COMM_FORCE")) c->force = atoi(env);
+    if (const char *env = getenv("SPDY_COMM_DRY")) c->dry = atoi(env);
     ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
     if (r != ncclSuccess) {
         delete c;
