@@ -169,6 +169,26 @@ def make_dynstep():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+def make_longrun():
+    """ref_run72.npz: first_step + 72 leapfrog steps (2 days at delt = 2400 s) of the flang-built reference's ADIABATIC step from
+    the reference's own rest state over a seeded orography, and from the same state with a seeded wind field (tests/longrun.py):
+    the prognostics after 1, 2, 4, 9, 18, 36 and 72 steps (ps whole, every second level / n / m of the 3-D fields)."""
+    import longrun
+    from oracle.pyoracle import Oracle
+    r = Reference("t30")
+    o = Oracle(r.trunc, r.ix, r.iy, r.kx)
+    d = {}
+    for case, amp in longrun.CASES.items():
+        st = longrun.rest_state(o, wind=amp)
+        out = longrun.run(lambda j1, j2, dt, s: r.step(j1, j2, dt, s)[0], r.tail_init, st)
+        for n, state in out.items():
+            for k, a in state.items():
+                d["%s_%d_%s" % (case, n, k)] = longrun.cut(k, a)
+    out = os.path.join(HERE, "ref_run72.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
 OUT_SUB = {"t30": (slice(None), slice(None), slice(None, None, 2)), "t30k5": (slice(None), slice(None), slice(None, None, 2)),
            "t63k16": (slice(None), slice(None, None, 3), slice(None, None, 4))}   # [kx, il, ix] sub-lattices kept per build
 OUT_SEED = 7000
@@ -269,6 +289,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "output":    # only the gridded-snapshot fixture
         make_output()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "longrun":   # only the 2-day run fixture
+        make_longrun()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "spectend":  # only the get_spectral_tendencies fixture
         make_spectend()
         sys.exit(0)
@@ -279,3 +302,4 @@ if __name__ == "__main__":
     make_spectend()
     make_dynstep()
     make_output()
+    make_longrun()

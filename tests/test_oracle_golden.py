@@ -302,6 +302,27 @@ def test_dynamics_step_pinned(tag, oracle_factory):
             assert np.array_equal(a if n == "psdt" else a[sub], z[key + n].reshape((a if n == "psdt" else a[sub]).shape)), (key, n)
 
 
+@pytest.mark.parametrize("case", ["rest", "wind"])
+def test_two_day_run_pinned(case, oracle_factory):
+    """BASELINE config 1's stand-in: first_step + 72 leapfrog steps (2 days) of the flang-built reference's adiabatic step from
+    the reference's own rest state over a seeded orography (tests/longrun.py; tests/golden/ref_run72.npz), against the oracle's
+    call-by-call step CHAINED over the same 74 steps: the prognostics after 1, 2, 4, 9, 18, 36 and 72 steps, BIT FOR BIT --
+    the restatement does not drift from the reference over a run, it IS the reference's arithmetic."""
+    import dynstep
+    import longrun
+    z, o = np.load(os.path.join(GOLDEN, "ref_run72.npz")), oracle_factory("t30")
+    st = longrun.rest_state(o, wind=longrun.CASES[case])
+    out = longrun.run(lambda j1, j2, dt, s: dynstep.oracle_dynamics_step(o, s, j1, dt, 0.0 if j1 == 1 else dynstep.ROB, j2=j2)[0],
+                      o.tail_init, st)
+    assert sorted(out) == list(longrun.CHECKPOINTS)
+    for n, state in out.items():
+        for k, a in state.items():
+            assert np.all(np.isfinite(a.view(float)))
+            assert np.array_equal(longrun.cut(k, a), z["%s_%d_%s" % (case, n, k)]), (case, n, k)
+    u, v = o.uvspec(out[72]["vor"][0, 0], out[72]["div"][0, 0])       # the run is not a trivial one: m/s at the top level
+    assert np.abs(o.spec_to_grid(u, 2)).max() > (10.0 if case == "wind" else 0.5)
+
+
 def test_dynamics_step_live(oracle_factory):
     """The same against the live flang build: the start-up sequence of first_step and a leapfrog step, chained, full arrays,
     bit for bit (build container only)."""
