@@ -177,6 +177,26 @@ def _time_us(torch, sp, fn, reps=20, warm=3):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def _time_graph_us(sp, fn, per_graph=10, reps=20, warm=3):
+    """The same as replays of ONE captured graph holding `per_graph` calls of fn(): what a launch costs a host that replays a
+    recorded sequence (no per-call issue cost of the eager ctypes path), wall clock around `reps` replays / (reps x per_graph)."""
+    sp.use_own_stream()
+    sp.synchronize()
+    with sp.graph_capture() as g:
+        for _ in range(per_graph):
+            fn()
+    for _ in range(warm):
+        g.launch()
+    sp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.launch()
+    sp.synchronize()
+    us = (time.perf_counter() - t0) / (reps * per_graph) * 1e6
+    g.close()
+    return us
+
+
 def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
     import numpy as np
     sp = s.Spectral(res, kx=kx, max_batch=4 * kx + 4, device=dev.index or 0)
@@ -248,11 +268,17 @@ def extras(s, torch, synth, sp, dev, args):
         out["direct_batch_6144"] = {"fields": 6144, "us": us, "GB/s": gb(byt, us), "frac_of_8TBs": gb(byt, us) / HBM_PEAK_GBS}
         # model-shaped batches of the T30 L8 step: 91 inverse (8 uvspec pairs + 75 plain), 73 direct
         # (24 vdspec pairs + 25 plain), 48 (8 pairs + 32 plain) -- latency-bound: microseconds per launch
+        # us_per_launch: back-to-back launches inside a replayed graph (what the captured step pays); us_per_launch_eager:
+        # the same launches issued one by one through ctypes (bound by the host's issue rate, not by the kernel)
         for name, (np_, npl) in (("inverse_91", (8, 75)), ("inverse_48", (8, 32))):
-            us = _time_us(torch, sp, lambda: sp.inverse_batch_dev(vor[:np_], div[:np_], ug[:np_], vg[:np_], pl_s[:npl], pl_g[:npl]), reps=50)
-            out[name] = {"fields": 2 * np_ + npl, "us_per_launch": us, "fields_per_s": (2 * np_ + npl) / (us * 1e-6)}
-        us = _time_us(torch, sp, lambda: sp.direct_batch_dev(ug[:24], vg[:24], vor[:24], div[:24], pl_g[:25], pl_s[:25]), reps=50)
-        out["direct_73"] = {"fields": 73, "us_per_launch": us, "fields_per_s": 73 / (us * 1e-6)}
+            fn = lambda: sp.inverse_batch_dev(vor[:np_], div[:np_], ug[:np_], vg[:np_], pl_s[:npl], pl_g[:npl])
+            eager = _time_us(torch, sp, fn, reps=50)
+            us = _time_graph_us(sp, fn)
+            out[name] = {"fields": 2 * np_ + npl, "us_per_launch": us, "us_per_launch_eager": eager, "fields_per_s": (2 * np_ + npl) / (us * 1e-6)}
+        fn = lambda: sp.direct_batch_dev(ug[:24], vg[:24], vor[:24], div[:24], pl_g[:25], pl_s[:25])
+        eager = _time_us(torch, sp, fn, reps=50)
+        us = _time_graph_us(sp, fn)
+        out["direct_73"] = {"fields": 73, "us_per_launch": us, "us_per_launch_eager": eager, "fields_per_s": 73 / (us * 1e-6)}
         del ug, vg, vor, div, pl_s, pl_g
     # the same round trip with spec_to_grid writing back over the input grids (what a time-stepping host does with its
     # work arrays): 274 MB instead of 500 MB touched per step, so part of it stays in the 256 MB Infinity Cache between the
@@ -293,13 +319,18 @@ def extras(s, torch, synth, sp, dev, args):
         sp2.grid_to_spec_dev(g2, s2)
         sp2.spec_to_grid_dev(s2, o2, kcos=1)
     us = _time_us(torch, sp2, rt, reps=100, warm=60)   # (a fresh plan's first ~50 round trips run 15 % slow: clocks, first touch)
+    us_replayed = _time_graph_us(sp2, rt, per_graph=20, reps=5, warm=1)
     sp2.set_profiling(True)
     for _ in range(20):
         rt()
     prof = {k: ms / max(c, 1) * 1e3 for k, (ms, c) in sp2.get_profile().items() if c}
     byt = 2 * nb2 * (sp2.ix * sp2.il * 8 + sp2.mx * sp2.nx * 16)
     out[other + "_round_trip"] = {"fields": nb2, "round_trips_per_s": nb2 / (us * 1e-6), "us_per_step": us, "kernel_us": prof,
-                                  "path_hbm_frac": gb(byt, us) / HBM_PEAK_GBS}
+                                  "path_hbm_frac": gb(byt, us) / HBM_PEAK_GBS,
+                                  "round_trips_per_s_replayed": nb2 / (us_replayed * 1e-6), "us_per_step_replayed": us_replayed,
+                                  "warmup": "60 untimed round trips, then 100 eager ones between two events (the headline line of "
+                                            "--res %s uses --warmup steps + timed blocks repeated until they converge; "
+                                            "`replayed`: 20 round trips per graph, 5 replays)" % other}
     sp2.close()
     del g2, s2, o2
     if not args.no_cpu_baseline:
@@ -364,6 +395,13 @@ def fortran_step_loop():
     """Leapfrog steps per second of a flang-built main loop over the `time_stepping` drop-in (device-resident prognostics,
     one captured graph per step; kx = 8, the reference's level count)."""
     import subprocess
+
+    def rate(exe, nsteps, **env):
+        o = subprocess.run([exe, "time", str(nsteps)], capture_output=True, text=True, timeout=180, env=dict(os.environ, SPDY_DEVICE="0", **env))
+        f = o.stdout.split()
+        if o.returncode != 0 or len(f) < 4:
+            raise RuntimeError("rc %d: %s" % (o.returncode, (o.stdout + o.stderr)[-300:]))
+        return {"steps_per_s": float(f[0]), "us_per_step": round(1e6 / float(f[0]), 2), "steps": int(f[1]), "kx": int(f[3])}
     res = {}
     for tag in ("t30", "t63"):
         exe = os.path.join(ROOT, "speedy.f90_amd", "fortran", "build", tag, "dropin_step")
@@ -371,12 +409,23 @@ def fortran_step_loop():
             res[tag] = {"error": "fortran/build/%s/dropin_step not built (flang absent at build time)" % tag}
             continue
         try:
-            o = subprocess.run([exe, "time", "2000"], capture_output=True, text=True, timeout=120, env=dict(os.environ, SPDY_DEVICE="0"))
-            f = o.stdout.split()
-            res[tag] = {"steps_per_s": float(f[0]), "us_per_step": round(1e6 / float(f[0]), 2), "steps": int(f[1]), "kx": int(f[3]),
-                        "what": "Fortran main loop: call step(2, 2, 2*delt) on device-resident prognostics (adiabatic core)"}
+            res[tag] = dict(rate(exe, 2000), what="Fortran main loop: call step(2, 2, 2*delt) on device-resident prognostics (adiabatic core)")
         except Exception as e:
             res[tag] = {"error": repr(e)}
+            continue
+        # the same loop as an UNMODIFIED host sees it: step() refreshes the host arrays of `prognostics` after every step
+        # (time_stepping%host_refresh_interval = 1 via $SPDY_HOST_REFRESH: a 1.3 MB / 5.6 MB download + a sync per step)
+        try:
+            res[tag]["host_arrays_current_every_step"] = rate(exe, 500, SPDY_HOST_REFRESH="1")
+        except Exception as e:
+            res[tag]["host_arrays_current_every_step"] = {"error": repr(e)}
+        # ... and with the host-physics hook (-DSPDY_WITH_PHYSICS build: phi, the level-1 prognostics and four grid tendency
+        # stacks come down, a stand-in get_physical_tendencies runs on the host, the tendencies go back up -- every step)
+        if os.path.exists(exe + "_phys"):
+            try:
+                res[tag]["with_host_physics_hook"] = dict(rate(exe + "_phys", 300), what="PCIe round trip of 10 level stacks + a stand-in physics per step (no graph)")
+            except Exception as e:
+                res[tag]["with_host_physics_hook"] = {"error": repr(e)}
     return res
 
 
@@ -653,7 +702,7 @@ def main():
         # HBM traffic per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own) -- the per-field
         # figure of the committed counter passes (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per launch / fields,
         # source file named there) times this run's batch; `traffic_source` says so
-        traffic, traffic_source = None, None
+        traffic, traffic_source, mfma_util, mfma_source = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -662,6 +711,17 @@ def main():
                 traffic = per_field * nb if per_field else None
                 if traffic:
                     traffic_source = "profiles/pmc_traffic.json (%s): rocprofv3 PMC passes of an earlier run of this command, bytes per field x %d fields; not measured in this run" % (tj.get("source", "committed"), nb)
+                # FP64 matrix-pipe utilisation of the dominant kernel: its matrix instructions are a fixed count per field
+                # (SQ_VALU_MFMA_BUSY_CYCLES of the committed counter pass: 16 cycles per v_mfma_f64_4x4x4_4b, summed over the
+                # SIMDs) -- divided by THIS run's launch duration x shader clock x SIMDs
+                busy = tj.get("counters", {}).get("%s/%s" % (args.res, dom), {}).get("mfma_busy_cycles_per_field")
+                if busy:
+                    props = torch.cuda.get_device_properties(dev)
+                    clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+                    simds = 4 * props.multi_processor_count
+                    mfma_util = busy * nb / (dom_ms * 1e-3 * clock_hz * simds)
+                    mfma_source = ("SQ_VALU_MFMA_BUSY_CYCLES per field of the committed PMC pass (%s) x %d fields / (this run's launch time x "
+                                   "%.2f GHz x %d SIMDs)" % (tj.get("source", "committed"), nb, clock_hz * 1e-9, simds))
             except Exception:
                 traffic = None
         res = {
@@ -681,6 +741,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": dom_ms, "bytes_per_launch": ab[dom] * nb,
+                         "mfma_util": mfma_util, "mfma_util_source": mfma_source,
                          "all_kernels_ms": kinds},
         }
     # N > 1 (every rank takes part; never fatal, never inside `value`): what a level-sharded step adds

@@ -172,7 +172,7 @@ int upload_all(spdy_plan *p)
     int rc;
 #define UP(vec, field) if ((rc = dev_upload(p, vec, &d.field))) return rc
     UP(inv, pa_inv); UP(dir, pa_dir); UP(t.cosgr, cosgr); UP(t.cosgr2, cosgr2); UP(t.coriol, coriol);
-    d.pa_inv2 = d.pa_dir2 = d.img_s2g = d.img_g2s = nullptr;
+    d.pa_inv2 = d.pa_dir2 = d.img_s2g = d.img_g2s = d.img_s2g3 = nullptr;
     if (t.trunc == 30) {
         std::vector<double> inv2, dir2;
         build_packed_tables(t, d.ks_inv, d.js_dir, inv2, dir2);
@@ -203,6 +203,26 @@ int upload_all(spdy_plan *p)
                 }
             }
         UP(is2g, img_s2g); UP(ig2s, img_g2s);
+        // small-batch form of the inverse kernel: per third of the latitudes one packed fragment per k-step (the construction of
+        // inv2 -- which is the third 16..23 -- at latitude offsets 0, 8, 16)
+        std::vector<double> is2g3((size_t)3 * 4 * 20 * 64, 0.0);
+        auto P = [&](int m, int n, int j) { return t.poly[m + t.mx * (n + (size_t)t.nx * j)]; };
+        for (int part = 0; part < 3; ++part)
+            for (int w = 0; w < 4; ++w)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int ai = 0;
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const int mc = std::min(mslot(sl, w), t.mx - 1);
+                        for (int ks = 0; ks < 4 - (sl >> 1); ++ks, ++ai) {
+                            const int blk = (lane >> 2) & 3, i = lane & 3, k = lane >> 4, par = blk >> 1;
+                            const int lat = 8 * part + 4 * (blk & 1) + i, n = 2 * (4 * ks + k) + par;
+                            double v = 0.0;
+                            if (lat < t.iy && n < t.nx && mc + n <= t.trunc + 1) v = P(mc, n, lat);
+                            is2g3[((size_t)((part * 4 + w) * 10 + ai / 2) * 64 + lane) * 2 + (ai & 1)] = v;
+                        }
+                    }
+                }
+        UP(is2g3, img_s2g3);
     }
     d.img_g2s63 = d.img_s2g63 = nullptr;
     if (t.trunc == 63) {
@@ -594,19 +614,35 @@ int spdy_dev_alloc(spdy_plan *p, size_t bytes, void **d_ptr)
     if (!d_ptr) return fail(SPDY_ERR_ARG, "null pointer");
     *d_ptr = nullptr;
     if (!bytes) return SPDY_OK;
-    HIP_TRY(hipMalloc(d_ptr, bytes));
-    HIP_TRY(hipMemsetAsync(*d_ptr, 0, bytes, p->stream));
-    return sync(p);
+    // recorded with the plan's own allocations: released by spdy_dev_free, or with the plan (a host that finalises its
+    // modules in the "wrong" order -- the plan before the state that lives in these buffers -- leaks nothing)
+    void *ptr = nullptr;
+    RC(dev_alloc(p, bytes, &ptr));
+    int rc = SPDY_OK;
+    if (hipMemsetAsync(ptr, 0, bytes, p->stream) != hipSuccess) rc = fail(SPDY_ERR_HIP, "hipMemsetAsync failed");
+    if (!rc) rc = sync(p);
+    if (rc) {
+        p->allocs.pop_back();
+        (void)hipFree(ptr);
+        return rc;
+    }
+    *d_ptr = ptr;
+    return SPDY_OK;
 }
 
 int spdy_dev_free(spdy_plan *p, void *d_ptr)
 {
+    if (!d_ptr) return SPDY_OK;
     NEED_DEVICE(p);
     NOT_CAPTURING(p, "spdy_dev_free");
-    if (!d_ptr) return SPDY_OK;
-    RC(sync(p));                       // work queued on the plan's stream may still use it
-    HIP_TRY(hipFree(d_ptr));
-    return SPDY_OK;
+    for (auto it = p->allocs.begin(); it != p->allocs.end(); ++it)
+        if (*it == d_ptr) {
+            RC(sync(p));               // work queued on the plan's stream may still use it
+            p->allocs.erase(it);
+            HIP_TRY(hipFree(d_ptr));
+            return SPDY_OK;
+        }
+    return fail(SPDY_ERR_ARG, "spdy_dev_free: not a live spdy_dev_alloc buffer of this plan");
 }
 
 int spdy_dev_upload(spdy_plan *p, void *d_dst, const void *src, size_t bytes)

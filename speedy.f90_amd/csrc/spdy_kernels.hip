@@ -873,6 +873,7 @@ static int fft_grid_limit(const DevPlan &p) { return 3 * (p.num_cu > 0 ? p.num_c
 static size_t legendre_inv_lds(const DevPlan &p) { return sizeof(double) * std::max(LEG_MG * (2 * 4 * p.ks_inv * 16 + 2), 32 * LEG_BT * 18); }
 static size_t legendre_dir_lds(const DevPlan &p) { return sizeof(double) * std::max(LEG_MG * (p.il * 16 + 2), p.nx * LEG_BT * 18); }
 
+__global__ void wave_placement_kernel(int *out);
 // Function attributes are per device: the plan calls this once after hipSetDevice (spdy_plan_create), so a second
 // plan on another GPU of the same process gets its own > 64 KB dynamic-LDS limits.
 hipError_t prepare_device_kernels()
@@ -881,12 +882,17 @@ hipError_t prepare_device_kernels()
 #define SPDY_K2(k_, m_, b_) {reinterpret_cast<const void *>(k_<m_, false>), b_}, {reinterpret_cast<const void *>(k_<m_, true>), b_}
         SPDY_K2(s2g_fused_t30_kernel, 0, t30::S2G_LDS), SPDY_K2(s2g_fused_t30_kernel, 1, t30::S2G_LDS),
         SPDY_K2(s2g_fused_t30_kernel, 2, t30::S2G_LDS), SPDY_K2(s2g_fused_t30_kernel, 3, t30::S2G_LDS),
+        {reinterpret_cast<const void *>(s2g_fused_t30_kernel<0, false, true>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<1, false, true>), t30::S2G_LDS},
+        {reinterpret_cast<const void *>(s2g_fused_t30_kernel<2, false, true>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<3, false, true>), t30::S2G_LDS},
         SPDY_K2(g2s_fused_t30_kernel, 0, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 1, t30::G2S_LDS),
         SPDY_K2(g2s_fused_t30_kernel, 2, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 3, t30::G2S_LDS),
         SPDY_K2(g2s_fused_t63_kernel, 0, t63::LDS_BYTES), SPDY_K2(g2s_fused_t63_kernel, 1, t63::LDS_BYTES),
 #undef SPDY_K2
         {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, false>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(s2g_fused_t63_kernel<true, false>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, true>), t63::LDS_BYTES},
+        // the two-workgroups-per-pair form of small direct batches (every model-sized T63 batch, the captured step)
+        {reinterpret_cast<const void *>(g2s_fused_t63_kernel<0, false, true>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(g2s_fused_t63_kernel<1, false, true>), t63::LDS_BYTES},
+        {reinterpret_cast<const void *>(wave_placement_kernel), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {
         hipError_t e = hipFuncSetAttribute(b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.bytes);
@@ -1041,12 +1047,7 @@ __global__ __launch_bounds__(512) void wave_placement_kernel(int *out)
 }
 hipError_t launch_wave_placement(int *d_out, int nwg, hipStream_t s)
 {
-    static bool once = false;
-    if (!once) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wave_placement_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, t63::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        once = true;
-    }
+    // (its dynamic-LDS limit is raised per device in prepare_device_kernels)
     hipLaunchKernelGGL(wave_placement_kernel, dim3(nwg), dim3(512), t63::LDS_BYTES, s, d_out);
     return hipGetLastError();
 }

@@ -21,6 +21,9 @@ struct DevPlan {
     // the same fragments in the order the fused T30 kernels keep them in registers, two per 16-byte load:
     const double *img_s2g;  // [4 Legendre waves][30][64 lanes][2]
     const double *img_g2s;  // [4 Legendre waves][36][64 lanes][2]
+    // the inverse kernel's small-batch form (work items = (tile, third of the latitudes)): per part the packed fragments of
+    // latitudes 8 part .. 8 part + 7 (blocks 0, 1: even n, blocks 2, 3: odd n), in slot order
+    const double *img_s2g3; // [3 parts][4 Legendre waves][10][64 lanes][2]
     // A-operand images of the fused T63 kernels: [4 Legendre waves][38 slots][6 chunks][64 lanes][2] (spdy_t63_sched.hpp)
     const double *img_g2s63, *img_s2g63;
     const double *cosgr;    // [il]

@@ -513,11 +513,12 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // (time_stepping.f90:62-167).  At model sizes each of the five kernels above is a ~6 us launch around a few hundred KB;
 // fused, the tendencies never leave the CU between them.  Block = BX (16) coefficients x kx level rows (kx <= 16): thread
 // (e, k) owns the tendencies of one coefficient at one level in registers; the level-coupled parts (vertical sums,
-// geopotential recursion, the kx x kx mat-vecs) go through LDS.  Every expression is the one of the separate kernel, so
-// the results are bit-identical to the unfused sequence.
+// geopotential recursion, the kx x kx mat-vecs) go through LDS.  Every expression is the one of the separate kernels in the
+// same order; the results agree with the unfused sequence to rounding (the compiler may contract a*b + c differently in the
+// two translation contexts: include/spdy.h states "to rounding", the tests hold both forms to 1e-12 against the oracle).
 // ------------------------------------------------------------------------------------------
-// NJ = 16-byte pieces of a mat-vec row held in registers: 4 for up to 8 levels (512 threads, 256 VGPRs), 8 for up to 16
-// (1024 threads, 128 VGPRs)
+// NJ = 16-byte pieces of a mat-vec row held in registers: 4 for up to 8 levels, 8 for up to 16; the block is STEP_BX (16)
+// coefficients x kx level rows = 128 / 256 threads (launch bounds: two blocks per CU at NJ = 8)
 // FULL: the level count IS the bound (8 or 16, the reference's and config 5's): every `kk < kx` guard and index clamp of the
 // unrolled level loops folds away.  The level recurrences are executed by ONE wave while the block waits, so their
 // instruction count (not a latency) is what the block pays: 1300 instructions at 4 cycles each were 2.7 us at kx = 16.

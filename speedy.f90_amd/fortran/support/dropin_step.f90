@@ -80,7 +80,12 @@ contains
     end subroutine
 
     subroutine dump
-        call prognostics_from_device
+        character(len=8) :: env
+        integer :: stat
+        ! DROPIN_UNMODIFIED_HOST: read the host arrays as the reference's main loop does, without asking for them
+        ! (they are current only if time_stepping%host_refresh_interval / $SPDY_HOST_REFRESH makes step() refresh them)
+        call get_environment_variable('DROPIN_UNMODIFIED_HOST', env, status=stat)
+        if (stat /= 0) call prognostics_from_device
         call tendencies_from_device(vordt, divdt, tdt, psdt, trdt)
         write(11) vor, div, t, tr, ps, phi, vordt, divdt, tdt, trdt, psdt
     end subroutine

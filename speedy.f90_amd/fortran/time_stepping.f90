@@ -21,8 +21,9 @@
 !  everything spectral stays on the GPU.  A step is then plain launches with one host section (no graph).
 !
 !  The host arrays of `prognostics` are uploaded at the first step (or by prognostics_to_device, after the model changed
-!  them) and are NOT kept current: call prognostics_from_device before reading vor, div, t, ps, tr, phi on the host
-!  (output, diagnostics, restart files).  tcorh/qcorh (horizontal_diffusion, filled by forcing.f90) and phis travel with
+!  them) and are by default NOT kept current: call prognostics_from_device before reading vor, div, t, ps, tr, phi on the host
+!  (output, diagnostics, restart files) -- or set host_refresh_interval / $SPDY_HOST_REFRESH (below) and leave the host's
+!  main loop as it is.  tcorh/qcorh (horizontal_diffusion, filled by forcing.f90) and phis travel with
 !  prognostics_to_device.
 module time_stepping
     use iso_c_binding
@@ -37,7 +38,17 @@ module time_stepping
     public first_step, step
     ! extensions (not in the reference)
     public prognostics_to_device, prognostics_from_device, tendencies_from_device, finalize_time_stepping
-    public output_fields_from_device
+    public output_fields_from_device, host_refresh_interval
+
+    !> Coherent mode for an UNMODIFIED host.  The reference's main loop reads the host arrays of `prognostics` right after
+    !  step() (speedy.f90:41 check_diagnostics, :44-50 output and the coupler); with the state in HBM those arrays go stale unless
+    !  the host calls prognostics_from_device.  host_refresh_interval = N > 0 makes step() itself refresh them (both time levels
+    !  and phi) after every N-th step: N = 1 is exactly the reference's semantics (at the price of 1.3 MB over PCIe
+    !  and a synchronisation per step), N = nsteps_out is enough for a host that only looks at the state when it writes
+    !  output.  0 (default): never -- the host calls prognostics_from_device where it needs the state.  The environment
+    !  variable SPDY_HOST_REFRESH sets the initial value, so that not even a recompile of the host is needed.
+    integer :: host_refresh_interval = -1
+    integer :: steps_since_refresh = 0
 
     integer(c_size_t), parameter :: spec_bytes = 16_c_size_t*mx*nx, grid_bytes = 8_c_size_t*ix*il
 
@@ -91,24 +102,46 @@ contains
         call enqueue_to_grid(j2)
         call host_physics
         call enqueue_from_grid(j1, dt, eps)
-        return
-#endif
+#else
         if (j1 /= 2) then                 ! the two start-up steps run once: plain launches
             call enqueue_step(j1, j2, dt, eps)
-            return
+        else
+            if (c_associated(graph) .and. (graph_j1 /= j1 .or. graph_j2 /= j2 .or. graph_dt /= dt)) then
+                call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
+                graph = c_null_ptr
+            end if
+            if (.not. c_associated(graph)) then
+                ! The implicit and damping tables are refreshed in place by initialize_implicit: the captured step sees them.
+                call spdy_check(spdy_graph_begin(spectral_plan), 'graph_begin')
+                call enqueue_step(j1, j2, dt, eps)
+                call spdy_check(spdy_graph_end(spectral_plan, graph), 'graph_end')
+                graph_j1 = j1; graph_j2 = j2; graph_dt = dt
+            end if
+            call spdy_check(spdy_graph_launch(graph), 'graph_launch')
         end if
-        if (c_associated(graph) .and. (graph_j1 /= j1 .or. graph_j2 /= j2 .or. graph_dt /= dt)) then
-            call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
-            graph = c_null_ptr
+#endif
+        call refresh_host_if_due(j1)
+    end subroutine
+
+    !> host_refresh_interval (above): the host arrays follow the device state every N-th leapfrog step.
+    subroutine refresh_host_if_due(j1)
+        integer, intent(in) :: j1          ! (unused: start-up steps count like leapfrog steps)
+        character(len=16) :: env
+        integer :: stat, n
+        if (host_refresh_interval < 0) then
+            host_refresh_interval = 0
+            call get_environment_variable('SPDY_HOST_REFRESH', env, status=stat)
+            if (stat == 0) then
+                read (env, *, iostat=stat) n
+                if (stat == 0 .and. n > 0) host_refresh_interval = n
+            end if
         end if
-        if (.not. c_associated(graph)) then
-            ! The implicit and damping tables are refreshed in place by initialize_implicit: the captured step sees them.
-            call spdy_check(spdy_graph_begin(spectral_plan), 'graph_begin')
-            call enqueue_step(j1, j2, dt, eps)
-            call spdy_check(spdy_graph_end(spectral_plan, graph), 'graph_end')
-            graph_j1 = j1; graph_j2 = j2; graph_dt = dt
+        if (host_refresh_interval <= 0) return
+        steps_since_refresh = steps_since_refresh + 1
+        if (steps_since_refresh >= host_refresh_interval) then
+            call prognostics_from_device
+            steps_since_refresh = 0
         end if
-        call spdy_check(spdy_graph_launch(graph), 'graph_launch')
     end subroutine
 
     !> One adiabatic step on the plan's stream (returns when it is queued).

@@ -223,6 +223,24 @@ def test_time_stepping_dropin_vs_oracle(tag, phys, tmp_path, oracle_factory):
             worst[n] = max(worst.get(n, 0.0), e)
             assert e <= TOL, (tag, rec, n, e)
     assert pos[0] == raw.size
+    if not phys:
+        # an UNMODIFIED host: its main loop reads the host arrays right after step() (speedy.f90:41-50) and never asks for a
+        # download.  With $SPDY_HOST_REFRESH=1 step() keeps them current itself (time_stepping%host_refresh_interval) -- same
+        # bytes as with explicit prognostics_from_device calls; without it they are stale (the initial state), which is what
+        # the option is for
+        fout2 = tmp_path / "out_unmodified.bin"
+        env = dict(os.environ, DROPIN_UNMODIFIED_HOST="1", SPDY_HOST_REFRESH="1")
+        r2 = subprocess.run([exe, str(fin), str(fout2), str(nleap)], capture_output=True, text=True, timeout=300, env=env)
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        raw2 = np.fromfile(fout2, np.float64).view(np.complex128)
+        nprog = (4 * 2 * kx + 2 + kx) * nx * mx                      # vor, div, t, tr, ps, phi of one record
+        rec_len = raw.size // (1 + nleap)
+        for rec in range(1 + nleap):
+            assert np.array_equal(raw2[rec * rec_len:][:nprog], raw[rec * rec_len:][:nprog]), rec
+        env.pop("SPDY_HOST_REFRESH")
+        r3 = subprocess.run([exe, str(fin), str(tmp_path / "out_stale.bin"), str(nleap)], capture_output=True, text=True, timeout=300, env=env)
+        stale = np.fromfile(tmp_path / "out_stale.bin", np.float64).view(np.complex128)
+        assert r3.returncode == 0 and not np.array_equal(stale[nleap * rec_len:][:nprog], raw[nleap * rec_len:][:nprog])
     # the gridded snapshot after the start-up sequence, from the device-resident prognostics (output_fields_from_device = the computing
     # lines of input_output.f90:183-205; the oracle's restatement of them is pinned bit for bit: test_output_fields_pinned).
     # the device state differs from the oracle's by ~1e-14, so a value next to a float32 rounding boundary may land on the

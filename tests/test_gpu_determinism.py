@@ -66,3 +66,43 @@ def test_wave_placement_assumption():
         assert bad == 0, (simd, bad)
         assert simd[:4] == simd[4:] and sorted(simd[:4]) == [0, 1, 2, 3], simd
     sp.close()
+
+
+@pytest.mark.parametrize("nb", [1, 2, 3, 16, 91, 170])
+def test_t30_small_batch_forms_agree(nb, monkeypatch):
+    """Small T30 inverse launches (at most a third as many tiles as CUs: every model-shaped launch, every one-field call) run by
+    (tile, third of the latitudes) work items -- csrc/spdy_fused_t30.inc, PART -- instead of whole tiles.  Every (latitude,
+    column) is the same chain of matrix instructions either way: the two forms must agree BIT FOR BIT, in every mode of the
+    kernel: plain fields with mixed kcos, uvspec pairs, gradients, and the mixed batch of a model step (pairs + gradient +
+    plain spectra from several arrays)."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral("t30", kx=8, max_batch=max(nb, 8), device=0)
+    dev = torch.device("cuda", 0)
+    S = torch.from_numpy(synth.spectra(max(nb, 4), sp.trunc, first=321, full_rows=True)).to(dev)
+    kc = torch.tensor([2 if b % 3 == 1 else 1 for b in range(nb)], dtype=torch.int32, device=dev)
+    npair = max(1, min(nb // 2, 24))
+    f64 = lambda n: torch.full((n, sp.il, sp.ix), float("nan"), dtype=torch.float64, device=dev)
+
+    def run():
+        out = {"plain": f64(nb), "ug": f64(npair), "vg": f64(npair), "gx": f64(npair), "gy": f64(npair),
+               "mug": f64(npair), "mvg": f64(npair), "mpl": f64(nb), "mgx": f64(1), "mgy": f64(1)}
+        sp.spec_to_grid_dev(S[:nb], out["plain"], d_kcos=kc)
+        sp.uvspec_to_grid_dev(S[:npair], S[npair:2 * npair] if 2 * npair <= S.shape[0] else S[:npair], out["ug"], out["vg"], 2)
+        sp.grad_to_grid_dev(S[:npair], out["gx"], out["gy"], 2)
+        n0 = nb // 2
+        segs = [S[:n0], S[n0:nb]] if n0 else [S[:nb]]
+        sp.inverse_batch_segs_dev(S[:npair], S[1:npair + 1], out["mug"], out["mvg"], segs, out["mpl"], S[2:3], out["mgx"], out["mgy"],
+                                  kcos_pairs=2, kcos=1)
+        sp.synchronize()
+        return out
+    a = run()
+    monkeypatch.setenv("SPDY_T30_NOPART", "1")
+    b = run()
+    monkeypatch.delenv("SPDY_T30_NOPART")
+    c = run()
+    for k in a:
+        assert not torch.isnan(a[k]).any(), k
+        assert torch.equal(a[k], b[k]), (nb, k)
+        assert torch.equal(a[k], c[k]), (nb, k)
+    sp.close()
