@@ -515,7 +515,7 @@ hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec
 // (e, k) owns the tendencies of one coefficient at one level in registers; the level-coupled parts (vertical sums,
 // geopotential recursion, the kx x kx mat-vecs) go through LDS.  Every expression is the one of the separate kernels in the
 // same order; the results agree with the unfused sequence to rounding (the compiler may contract a*b + c differently in the
-// two translation contexts: include/spdy.h states "to rounding", the tests hold both forms to 1e-12 against the oracle).
+// two translation contexts: include/spdy.h states "to rounding", the tests hold both forms to 1e-12 against the CPU checker).
 // ------------------------------------------------------------------------------------------
 // NJ = 16-byte pieces of a mat-vec row held in registers: 4 for up to 8 levels, 8 for up to 16; the block is STEP_BX (16)
 // coefficients x kx level rows = 128 / 256 threads (launch bounds: two blocks per CU at NJ = 8)
