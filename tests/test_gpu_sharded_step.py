@@ -151,6 +151,79 @@ def test_sharded_step_in_process_ranks(tag, world, oracle_factory, monkeypatch):
     assert worst <= TOL, (tag, world, worst)
 
 
+def _physics_increment(kx, il, ix):
+    """A seeded stand-in for get_physical_tendencies (tendencies.f90:203-206 adds to utend, vtend, ttend, trtend in grid space)."""
+    rng = np.random.default_rng(77)
+    return [rng.uniform(-1.0, 1.0, (kx, il, ix)) * sc for sc in (1e-5, 1e-5, 1e-4, 1e-8)]
+
+
+def _hook_thread(rank, group, st, results, errors):
+    import torch
+    import speedy_f90_amd as s
+    try:
+        sp = make_plan("t30")
+        sp.use_own_stream()
+        comm = s.sharding.LevelComm(sp, group=group, rank=rank)
+        kx = sp.kx
+        D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
+        phi = torch.zeros((kx, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+        inc = [torch.from_numpy(a).cuda() for a in _physics_increment(kx, sp.il, sp.ix)]
+        torch.cuda.synchronize()
+        comm.sharded_step_grid_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], 2)
+        sp.synchronize()
+        U, V, PL, lo, hi = comm.sharded_step_operands()          # this rank's levels only: [utend | ..], [vtend | ..], [KE | ttend | trtend | ps]
+        nl = hi - lo
+        U[:nl] += inc[0][lo:hi]; V[:nl] += inc[1][lo:hi]; PL[nl:2 * nl] += inc[2][lo:hi]; PL[2 * nl:3 * nl] += inc[3][lo:hi]
+        torch.cuda.synchronize()
+        comm.sharded_step_spectral_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, DT, ROB, WIL, phi)
+        sp.synchronize()
+        results[rank] = {n: D[n].cpu().numpy() for n in PROGS}
+        comm.close(); sp.close()
+    except Exception as e:
+        errors[rank] = e
+
+
+def test_sharded_step_physics_hook(monkeypatch):
+    """The two halves of the sharded step with a host "physics" in between (the hook of tendencies.f90:203-206): every rank adds
+    its grid-space increments to ITS levels' operands (spdy_sharded_step_operands); the result must equal, bit for bit, the
+    unsharded three-call step with the same increments added to the full operands."""
+    import torch
+    import speedy_f90_amd as s
+    monkeypatch.setenv("SPDY_COMM_TIMEOUT_S", "60")
+    sp = make_plan("t30")
+    kx, nx, mx, il, ix = sp.kx, sp.nx, sp.mx, sp.il, sp.ix
+    st = state(sp, 8000)
+    D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
+    P = 3 * kx
+    c128 = lambda *shape: torch.zeros(shape, dtype=torch.complex128, device="cuda")
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device="cuda")
+    ug, vg, plain_g, px, py = f64(kx, il, ix), f64(kx, il, ix), f64(4 * kx, il, ix), f64(1, il, ix), f64(1, il, ix)
+    U, V, PL = f64(P, il, ix), f64(P, il, ix), f64(P + 1, il, ix)
+    pvor, pdiv, pspec, phi = c128(P, nx, mx), c128(P, nx, mx), c128(P + 1, nx, mx), c128(kx, nx, mx)
+    inc = [torch.from_numpy(a).cuda() for a in _physics_increment(kx, il, ix)]
+    sp.inverse_batch_segs_dev(D["vor"][1], D["div"][1], ug, vg, [D[n][1] for n in ("vor", "div", "t", "tr")], plain_g, D["ps"][1:2], px, py,
+                              kcos_pairs=2, kcos=1)
+    sp.grid_tendencies_dev(ug, vg, plain_g[2 * kx:3 * kx], plain_g[:kx], plain_g[kx:2 * kx], plain_g[3 * kx:], px, py, U, V, PL)
+    U[:kx] += inc[0]; V[:kx] += inc[1]; PL[kx:2 * kx] += inc[2]; PL[2 * kx:3 * kx] += inc[3]
+    sp.direct_batch_spectral_step_dev(U, V, PL, pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"],
+                                      SDRAG, 2, DT, ROB, WIL, phi, kcos=2)
+    torch.cuda.synchronize()
+    whole = {n: D[n].cpu().numpy() for n in PROGS}
+    group = s.sharding.LocalGroup(sp.lib, 2)
+    results, errors = {}, {}
+    threads = [threading.Thread(target=_hook_thread, args=(r, group, st, results, errors)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    group.close(); sp.close()
+    for r in range(2):
+        for n in PROGS:
+            assert np.array_equal(results[r][n], whole[n]), (r, n, synth.relerr(results[r][n], whole[n]))
+            assert not np.array_equal(whole[n], st[n])
+
+
 def test_in_process_group_errors():
     """A rank that never shows up breaks the group after the timeout (SPDY_ERR_COMM) instead of hanging its peers; collectives of
     an in-process communicator are refused inside a graph capture; a group cannot be destroyed under its communicators."""
