@@ -71,6 +71,7 @@ enum {
  *   SPDY_DEVICE        device index for SPDY_DEVICE_AUTO              SPDY_FUSED = 0 | 1   initial spdy_plan_set_fused mode
  *   SPDY_WG_PER_CU     persistent workgroups per CU of the T30 kernels (default 1)
  *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1     SPDY_T63_NOSPLIT     one workgroup per pair in small
+ *   SPDY_T63_NOSTAGE   small T63 direct batches run fused (row FFTs inside the contraction launch) instead of staged (same bits)
  *   SPDY_T30_NOPART    small T30 inverse launches walk whole tiles instead of (tile, third of the latitudes) items (same bits)
  *   SPDY_COMM_DRY=1    RCCL communicators created under it skip their                      T63 direct launches (same bits)
  *                      collectives (timing a sharded step without its exchanges; results are then wrong)

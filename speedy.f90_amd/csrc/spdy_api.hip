@@ -225,10 +225,19 @@ int upload_all(spdy_plan *p)
         UP(is2g3, img_s2g3);
     }
     d.img_g2s63 = d.img_s2g63 = nullptr;
+    d.rows_ws = nullptr; d.rows_ws_fields = 0;
     if (t.trunc == 63) {
         std::vector<double> i63d, i63i;
         build_t63_images(t, i63d, i63i);
         UP(i63d, img_g2s63); UP(i63i, img_s2g63);
+        // row workspace of the staged small-batch direct transform (spdy_fused_t63.inc): a model step's direct batch is up to
+        // three segments of at most max_batch fields, and the form only runs below one pair per two CUs -- model-shaped plans
+        // get room for all of it (98 KB per field), throughput-sized plans for the 256 fields such a launch can have
+        const size_t fields = std::min<size_t>((size_t)3 * p->max_batch + 2, 258);
+        void *ws = nullptr;
+        if ((rc = dev_alloc(p, fields * t.il * 2 * t.mx * sizeof(double), &ws))) return rc;
+        d.rows_ws = static_cast<double *>(ws);
+        d.rows_ws_fields = (int)fields;
     }
     UP(t.el2, el2); UP(t.elm2, elm2); UP(t.trfilt, trfilt); UP(t.gradx, gradx); UP(t.gradym, gradym);
     UP(t.gradyp, gradyp); UP(t.uvdx, uvdx); UP(t.uvdym, uvdym); UP(t.uvdyp, uvdyp); UP(t.vddym, vddym);

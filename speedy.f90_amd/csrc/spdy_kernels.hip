@@ -892,6 +892,7 @@ hipError_t prepare_device_kernels()
         {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, true>), t63::LDS_BYTES},
         // the two-workgroups-per-pair form of small direct batches (every model-sized T63 batch, the captured step)
         {reinterpret_cast<const void *>(g2s_fused_t63_kernel<0, false, true>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(g2s_fused_t63_kernel<1, false, true>), t63::LDS_BYTES},
+        {reinterpret_cast<const void *>(g2s_rows_t63_kernel<0>), (4 * 16 * t63::RS + t63::TW) * 8 + 4 * 68}, {reinterpret_cast<const void *>(g2s_rows_t63_kernel<1>), (4 * 16 * t63::RS + t63::TW) * 8 + 4 * 68},
         {reinterpret_cast<const void *>(wave_placement_kernel), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {

@@ -106,3 +106,41 @@ def test_t30_small_batch_forms_agree(nb, monkeypatch):
         assert torch.equal(a[k], b[k]), (nb, k)
         assert torch.equal(a[k], c[k]), (nb, k)
     sp.close()
+
+
+@pytest.mark.parametrize("nb", [1, 2, 9, 73, 146, 255])
+def test_t63_small_direct_forms_agree(nb, monkeypatch):
+    """Small T63 direct batches (at most half as many pairs as CUs) run STAGED -- the row FFTs as a launch of their own over
+    (pair, chunk, field) items, then the fused kernel's Legendre waves fed by movers (csrc/spdy_fused_t63.inc) -- instead of one
+    fused launch whose eight steps are each as long as one FFT wave's phase.  Same code for every row, same accumulation order:
+    the staged form, the fused split form (SPDY_T63_NOSTAGE) and a large batch's whole-pair walk must agree BIT FOR BIT, for plain
+    fields, for the scaled pairs of vdspec and for a model step's three-segment direct batch."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral("t63", kx=8, max_batch=600, device=0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4321)
+    G = torch.from_numpy(rng.uniform(-0.5, 0.5, (600, sp.il, sp.ix))).to(dev)
+    npair = max(1, min(nb // 3, 48))
+    c128 = lambda n: torch.full((n, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
+
+    def run():
+        out = {"plain": c128(nb), "vor": c128(npair), "div": c128(npair), "mvor": c128(npair), "mdiv": c128(npair), "mpl": c128(nb)}
+        sp.grid_to_spec_dev(G[:nb], out["plain"])
+        sp.vdspec_dev(G[:npair], G[npair:2 * npair], out["vor"], out["div"], 2)
+        sp.direct_batch_dev(G[:npair], G[npair:2 * npair], out["mvor"], out["mdiv"], G[100:100 + nb], out["mpl"], kcos=2)
+        sp.synchronize()
+        return out
+    a = run()
+    monkeypatch.setenv("SPDY_T63_NOSTAGE", "1")
+    b = run()
+    monkeypatch.delenv("SPDY_T63_NOSTAGE")
+    for k in a:
+        assert not torch.isnan(torch.view_as_real(a[k])).any(), k
+        assert torch.equal(a[k], b[k]), (nb, k)
+    # ... and inside a batch large enough for the whole-pair walk of the throughput form
+    big = c128(600)
+    sp.grid_to_spec_dev(G, big)
+    sp.synchronize()
+    assert torch.equal(big[:nb], a["plain"])
+    sp.close()
