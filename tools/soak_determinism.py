@@ -10,7 +10,7 @@ import torch
 import speedy_f90_amd as s
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-for res, nb in (("t63", 1536), ("t63", 146), ("t63", 9), ("t30", 6144), ("t30", 91)):
+for res, nb in (("t63", 1536), ("t63", 146), ("t63", 72), ("t63", 9), ("t30", 6144), ("t30", 91), ("t30", 3)):   # 146 / 72 / 9: the staged direct form (two / one pair per contraction workgroup); t30 91 / 3: the inverse kernel by latitude thirds
     sp = s.Spectral(res, kx=8, max_batch=nb, device=0)
     sp.use_torch_stream()
     torch.manual_seed(11)
