@@ -523,7 +523,9 @@ def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from dynstep import ROB, SDRAG, WIL
     import longrun
-    st = longrun.rest_state(sp, wind=longrun.CASES["wind"])     # (stays an atmosphere over the replays: tests/longrun.py)
+    sp_small = s.Spectral("t30", kx=kx, max_batch=8, device=dev.index or 0)     # (host-pointer calls: not on the 6144-field plan's staging)
+    st = longrun.rest_state(sp_small, wind=longrun.CASES["wind"])               # stays an atmosphere over the replays: tests/longrun.py
+    sp_small.close()
     sp.use_own_stream()
 
     def fresh():
