@@ -67,11 +67,12 @@ def unsharded_device_steps(sp, st, nsteps):
     return out
 
 
-def _rank_thread(rank, group, tag, st, nsteps, results, errors):
+def _rank_thread(rank, group, tag, st, nsteps, results, errors, device=0):
     import torch
     import speedy_f90_amd as s
     try:
-        sp = make_plan(tag)
+        torch.cuda.set_device(device)          # (per thread: the tensors below live on the rank's device)
+        sp = make_plan(tag, device)
         sp.use_own_stream()
         comm = s.sharding.LevelComm(sp, group=group, rank=rank)
         comm.sharded_step_workspace()
@@ -149,6 +150,35 @@ def test_sharded_step_in_process_ranks(tag, world, oracle_factory, monkeypatch):
     print("\n[sharded step %s, %d in-process ranks] worst relative error vs the oracle %.1e; bits equal to the unsharded device step"
           % (tag, world, worst))
     assert worst <= TOL, (tag, world, worst)
+
+
+def test_sharded_step_in_process_ranks_on_several_devices(oracle_factory, monkeypatch):
+    """The in-process group with one DEVICE per rank -- what a single-process host driving several GPUs runs: the exchanges are
+    peer copies (hipMemcpyPeerAsync) between the ranks' streams.  Skipped on 1-GPU boxes."""
+    import torch
+    import speedy_f90_amd as s
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs, %d visible" % torch.cuda.device_count())
+    monkeypatch.setenv("SPDY_COMM_TIMEOUT_S", "60")
+    tag, nsteps = "t30", 2
+    o = oracle_factory(tag)
+    o.tail_init(DT)
+    sp0 = make_plan(tag)
+    st = state(sp0, 8000)
+    whole = unsharded_device_steps(sp0, st, nsteps)
+    group = s.sharding.LocalGroup(sp0.lib, world)
+    results, errors = {}, {}
+    threads = [threading.Thread(target=_rank_thread, args=(r, group, tag, st, nsteps, results, errors, r)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    group.close(); sp0.close()
+    for r in range(world):
+        for n in PROGS + ("phi", "tend"):
+            assert np.array_equal(results[r][n], whole[n]), (r, n)
 
 
 def _physics_increment(kx, il, ix):
