@@ -9,7 +9,8 @@ implicit.f90:174-216.
 What runs where:
   * ranks INSIDE this process (spdy_comm_create_local: one thread + one plan per rank, all on device 0) -- real multi-rank
     runs of the very entry point an RCCL rank calls, on a 1-GPU box: world 1, 2 (equal blocks), 3 (ragged blocks), T30 L8,
-    T30 L5 and T63 L16 (the raw-pairs route of the T63 direct batch).  The exchanged stacks are NaN-poisoned between steps:
+    T30 L5 and T63 L16 (the raw-pairs route of the T63 direct batch); world 8 -- config 3's rank count: one level per rank at
+    T30 L8, two at T63 L16.  The exchanged stacks are NaN-poisoned between steps:
     a level that a rank neither computed nor received would poison its result.
   * RCCL at world size 1 with SPDY_COMM_FORCE (the collectives are really issued, both routes), eager and captured into a graph.
   * RCCL ranks in separate processes (world 2 and 3) where the box has the GPUs (skipped otherwise).
@@ -102,8 +103,7 @@ def _rank_thread(rank, group, tag, st, nsteps, results, errors, device=0):
         errors[rank] = e
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-@pytest.mark.parametrize("tag", ["t30", "t30k5", "t63k16"])
+@pytest.mark.parametrize("tag,world", [(t, w) for t in ("t30", "t30k5", "t63k16") for w in (1, 2, 3)] + [("t30", 8), ("t63k16", 8)])
 def test_sharded_step_in_process_ranks(tag, world, oracle_factory, monkeypatch):
     import speedy_f90_amd as s
     monkeypatch.setenv("SPDY_COMM_TIMEOUT_S", "60")
