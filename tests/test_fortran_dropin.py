@@ -260,3 +260,51 @@ def test_time_stepping_dropin_vs_oracle(tag, phys, tmp_path, oracle_factory):
     assert flips <= snap.size // 2000, flips
     worst["snapshot_flips"] = float(flips)
     print("\n[time_stepping drop-in %s%s] worst relative errors: " % (tag, " + host physics" if phys else "") + " ".join("%s %.1e" % kv for kv in worst.items()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["t30", "t63"])
+def test_sharded_step_from_one_fortran_process(tag, tmp_path, oracle_factory):
+    """One flang-built process, one OpenMP thread + plan per rank (support/dropin_step_sharded.f90): each leapfrog step is one
+    spdy_sharded_step_dev call per rank through the ISO_C_BINDING interfaces (spdy_c.f90), the ranks joined by an in-process
+    group.  The driver itself fails unless every rank ends with the same bytes; here: 1, 2, 3 and 8 ranks give the same
+    bytes as each other (the transforms are level-independent, whoever runs them) and hold the north star's 1e-12 against
+    the oracle's call-by-call step(2, 2, 2*delt) (time_stepping.f90:35-118)."""
+    from dynstep import ROB, state, oracle_dynamics_step, wave_relerr
+    exe = os.path.join(FDIR, "build", tag, "dropin_step_sharded")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built (no flang on this box and no prebuilt binary)")
+    o = oracle_factory(tag)
+    nx, mx, kx = o.nx, o.mx, o.kx
+    st = state(o, 8100)
+    fin = tmp_path / "in.bin"
+    with open(fin, "wb") as f:
+        for n in ("vor", "div", "t", "tr", "ps", "phis", "tcorh", "qcorh"):
+            f.write(np.ascontiguousarray(st[n]).tobytes())
+    nleap = 2
+    env = dict(os.environ, SPDY_COMM_TIMEOUT_S="60")
+    raws = {}
+    for world in (1, 2, 3, 8):
+        fout = tmp_path / ("out%d.bin" % world)
+        r = subprocess.run([exe, str(fin), str(fout), str(nleap), str(world)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count("transforms levels") == world, r.stdout
+        raws[world] = np.fromfile(fout, np.float64).view(np.complex128)
+        assert np.array_equal(raws[world].view(np.int64), raws[1].view(np.int64)), world
+    delt = float(np.float32(86400.0) / np.float32(36))               # params.f90:31
+    o.tail_init(2 * delt)
+    ref = st
+    for _ in range(nleap):
+        ref, out = oracle_dynamics_step(o, ref, 2, 2 * delt, ROB, j2=2)
+    raw, pos, worst = raws[1], 0, {}
+    shapes = [(n, (2, kx, nx, mx)) for n in ("vor", "div", "t", "tr")] + [("ps", (2, nx, mx)), ("phi", (kx, nx, mx))] + \
+             [(n, (kx, nx, mx)) for n in ("vordt", "divdt", "tdt", "trdt")] + [("psdt", (nx, mx))]
+    for n, shape in shapes:
+        a = raw[pos:pos + int(np.prod(shape))].reshape(shape)
+        pos += a.size
+        want = ref[n] if n in ref and n != "phi" else out[n]
+        worst[n] = max(synth.relerr(a, want), wave_relerr(a, want))
+        assert worst[n] <= TOL, (tag, n, worst[n])
+    assert pos == raw.size
+    print("\n[sharded step from one Fortran process, %s, 1/2/3/8 ranks bit-equal] worst relative errors: " % tag
+          + " ".join("%s %.1e" % kv for kv in worst.items()))
