@@ -25,8 +25,8 @@ buf = np.zeros(2 * 8 * 8 * 8, np.int64)
 sp.lib.spdy_debug_phase_trace(buf.ctypes.data_as(ctypes.c_void_p))
 t = buf.reshape(2, 8, 8, 8)[..., :8]   # kernel, step, mark, wave (0-3 Legendre, 4-6 FFT)
 for k, kn in enumerate(("s2g_fused", "g2s_fused")):
-    print("==", kn, "(cycles since the earliest mark of the step, per wave; steps 1..4; -1 = mark not hit)")
-    for it in range(1, 5):
+    print("==", kn, "(cycles since the earliest mark of the step, per wave; steps 1..4 (TRACE_TAIL=1: the last eight); -1 = mark not hit)")
+    for it in (range(0, 7) if os.environ.get("TRACE_TAIL") else range(1, 5)):   # TRACE_TAIL: a -DSPDY_TRACE_TAIL build (last 8 steps)
         live = t[k, it][t[k, it] > 0]
         if not live.size:
             continue
@@ -50,6 +50,23 @@ for k, kn in enumerate(("s2g_fused", "g2s_fused")):
             tops = [int(v - t0) for v in row[1:26] if v > 0]
             pro = [int(v - t0) if v > 0 else -1 for v in row[26:31]]
             print("   %-16s entry 0 | prologue marks %s | step tops %s | exit %d" % (role, pro, tops, int(row[31] - t0)))
+# entry / exit of every workgroup of the last launch of each kernel (100 MHz counter): dispatch ramp and finishing spread
+if hasattr(sp.lib, "spdy_debug_wg_span"):
+    span = np.zeros(2 * 512 * 2, np.int64)
+    sp.lib.spdy_debug_wg_span(span.ctypes.data_as(ctypes.c_void_p))
+    span = span.reshape(2, 512, 2)
+    for k, kn in enumerate(("s2g_fused", "g2s_fused")):
+        v = span[k][span[k][:, 0] > 0]
+        if not len(v):
+            continue
+        t0 = v[:, 0].min()
+        ent, ex = (v[:, 0] - t0) / 100.0, (v[:, 1] - t0) / 100.0
+        q = lambda a: " ".join("%.2f" % x for x in np.percentile(a, [0, 10, 50, 90, 100]))
+        d = ex - ent
+        print("   per XCD (workgroup %% 8): median duration " + " ".join("%.1f" % np.median(d[x::8]) for x in range(8))
+              + " | slowest workgroups " + " ".join("%d(%.1f)" % (i, d[i]) for i in np.argsort(d)[-8:]))
+        print("== workgroup spans %s (%d workgroups; us after the first entry; min p10 p50 p90 max): entry %s | exit %s | duration %s"
+              % (kn, len(v), q(ent), q(ex), q(ex - ent)))
 # the same launches timed with events, for the tick rate
 sp.set_profiling(True)
 for _ in range(5):
