@@ -111,7 +111,8 @@ struct T63Seg {
 enum { T63_OP_NONE = 0, T63_OP_U = 1, T63_OP_V = 2, T63_OP_GX = 3, T63_OP_GY = 4 };
 struct T63Batch {
     int nseg, npairs;
-    int by_chunk, pad;     // inverse, small batches: work items are (pair, chunk) instead of whole pairs (set by the launcher)
+    int by_chunk, wt;      // inverse, small batches: work items are (pair, chunk) instead of whole pairs; model-sized launches with
+                           // several MB of output: stores written through (both set by the launcher)
     T63Seg seg[T63_MAX_SEG];
 };
 hipError_t launch_s2g_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
@@ -176,6 +177,9 @@ struct GridTend {
     LevelShard sh;
 };
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
+// Write-through policy of a model-sized launch (the step's kernels): outputs of at least SPDY_WT_MIN_MB (default 6; env
+// override, 0 = never) leave the L2s as they are produced instead of waiting, dirty, for the end-of-kernel release.
+bool write_through_policy(long output_bytes);
 hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec, hipStream_t s);
 // the whole spectral-space tail of a step in one launch (kx <= 16)
 struct SpecStep {

@@ -361,7 +361,7 @@ __device__ __forceinline__ LevelBlock level_block(int k, int kx, int R)
     return LevelBlock{r, lo, (kx * (r + 1)) / R - lo};
 }
 
-template <int KM, bool FULL, bool SH>
+template <int KM, bool FULL, bool SH, bool WT = false>
 __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, GridTend g)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -447,14 +447,17 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
         tq1 = sig1 * (S(sq, k + 1) - tr_c);
         if (k + 1 == 1 || k + 1 == 2) tq1 = 0.0;
     }
-    LV(g.u, ok) = vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr;                         // utend (:160-161)
-    LV(g.v, ok) = -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr;                        // vtend (:170-171)
-    LV(g.plain, og + ok) = tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
-                           + akap * (tg_c * puv - tgg * dmean);                            // ttend (:181-184)
-    LV(g.plain, 2 * og + ok) = tr_c * dv - (tq1 + tq) * dhr;                               // trtend (:194)
-    LV(g.plain, ok) = 0.5 * (ug_c * ug_c + vg_c * vg_c);                                   // kinetic energy (:220)
-    LV(g.u, og + ok) = -ug_c * tgg;  LV(g.v, og + ok) = -vg_c * tgg;                       // (:224)
-    LV(g.u, 2 * og + ok) = -ug_c * tr_c;  LV(g.v, 2 * og + ok) = -vg_c * tr_c;             // (:229)
+    // (WT: a launch with several MB of output writes it through, launch_grid_tendencies)
+#define GT_ST(a_, k_, v_) do { if (WT) st1_wt(&LV(a_, k_), (v_)); else LV(a_, k_) = (v_); } while (0)
+    GT_ST(g.u, ok, vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr);                       // utend (:160-161)
+    GT_ST(g.v, ok, -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr);                      // vtend (:170-171)
+    GT_ST(g.plain, og + ok, tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
+                            + akap * (tg_c * puv - tgg * dmean));                          // ttend (:181-184)
+    GT_ST(g.plain, 2 * og + ok, tr_c * dv - (tq1 + tq) * dhr);                             // trtend (:194)
+    GT_ST(g.plain, ok, 0.5 * (ug_c * ug_c + vg_c * vg_c));                                 // kinetic energy (:220)
+    GT_ST(g.u, og + ok, -ug_c * tgg);  GT_ST(g.v, og + ok, -vg_c * tgg);                   // (:224)
+    GT_ST(g.u, 2 * og + ok, -ug_c * tr_c);  GT_ST(g.v, 2 * og + ok, -vg_c * tr_c);         // (:229)
+#undef GT_ST
 #undef LV
 #undef S
 }
@@ -478,10 +481,17 @@ hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream
         constexpr int bx = GT_BX;
         const dim3 grd((gsz + bx - 1) / bx), blk(bx, p.kx);
         const size_t lds = grid_tendencies_lds(p.kx, bx);
-        if (p.kx == 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, true, false>), grd, blk, lds, s, p, g);
-        else if (p.kx < 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, false, false>), grd, blk, lds, s, p, g);
-        else if (p.kx == 16) hipLaunchKernelGGL((grid_tendencies_kernel<16, true, false>), grd, blk, lds, s, p, g);
-        else hipLaunchKernelGGL((grid_tendencies_kernel<16, false, false>), grd, blk, lds, s, p, g);
+        const bool wt = write_through_policy((long)(9 * p.kx + 1) * gsz * 8);     // the launch's output: [3kx] + [3kx] + [3kx+1] grids
+#define GT_LAUNCH(KM_, FULL_)                                                                                     \
+    do {                                                                                                          \
+        if (wt) hipLaunchKernelGGL((grid_tendencies_kernel<KM_, FULL_, false, true>), grd, blk, lds, s, p, g);    \
+        else hipLaunchKernelGGL((grid_tendencies_kernel<KM_, FULL_, false, false>), grd, blk, lds, s, p, g);      \
+    } while (0)
+        if (p.kx == 8) GT_LAUNCH(8, true);
+        else if (p.kx < 8) GT_LAUNCH(8, false);
+        else if (p.kx == 16) GT_LAUNCH(16, true);
+        else GT_LAUNCH(16, false);
+#undef GT_LAUNCH
     }
     return hipGetLastError();
 }
