@@ -243,6 +243,16 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
             "state_finite_after_replays": finite}
 
 
+def headline_grids(torch, synth, sp, nb, rank, dev):
+    """The metric's synthetic input: 64 seeded white-noise templates tiled and rescaled per field."""
+    uniq = 64
+    tmpl = torch.from_numpy(synth.grids(uniq, sp.ix, sp.il, first=rank * uniq)).to(dev)
+    reps = (nb + uniq - 1) // uniq
+    grid = tmpl.repeat(reps, 1, 1)[:nb].contiguous()
+    grid *= (1.0 + torch.arange(nb, dtype=torch.float64, device=dev).view(nb, 1, 1) / nb)
+    return grid
+
+
 def extras(s, torch, synth, sp, dev, args):
     """Side measurements the N=1 line carries outside `value`: the kernels a real model step uses
     (operator-fused and mixed-batch modes, model-shaped batch sizes) and the other resolution."""
@@ -295,6 +305,40 @@ def extras(s, torch, synth, sp, dev, args):
     us = _time_us(torch, sp, rt_in_place, reps=50, warm=10)
     out["round_trip_in_place"] = {"fields": nbi, "round_trips_per_s": nbi / (us * 1e-6), "us_per_step": us}
     del gi, si
+    # How a launch's time splits into a fixed part (launch boundary, pipeline fill and drain) and a per-field part: the same two
+    # kernels at half and at twice the metric's batch.  The slope is the kernels' steady-state rate, what `roofline.frac`
+    # would be without the fixed part at B = 6144 (T30) / 1536 (T63).
+    try:
+        base = 6144 if sp.trunc == 30 else 1536
+        pts = {}
+        for nbs in (base // 2, base, 2 * base):
+            sps = s.Spectral("t30" if sp.trunc == 30 else "t63", kx=8, max_batch=nbs, device=dev.index or 0)
+            sps.use_own_stream()
+            gs = headline_grids(torch, synth, sps, nbs, 0, dev)     # (the same fields as the headline: run time depends on the data)
+            ss = torch.zeros((nbs, sps.nx, sps.mx), dtype=torch.complex128, device=dev)
+            os_ = torch.zeros_like(gs)
+            torch.cuda.synchronize()
+
+            def rts():
+                sps.grid_to_spec_dev(gs, ss)
+                sps.spec_to_grid_dev(ss, os_, kcos=1)
+            _time_us(torch, sps, rts, reps=100, warm=100)     # (a fresh plan's first round trips run slow: clocks, first touch)
+            sps.set_profiling(True)
+            for _ in range(30):
+                rts()
+            pts[nbs] = {k: ms / max(c, 1) * 1e3 for k, (ms, c) in sps.get_profile().items() if c}
+            sps.close()
+            del gs, ss, os_
+        bpf = sp.ix * sp.il * 8 + sp.mx * sp.nx * 16
+        fit = {}
+        for k in pts[base]:
+            slope = (pts[2 * base][k] - pts[base // 2][k]) / (1.5 * base)              # us per field
+            fit[k] = {"us_fixed": pts[base][k] - slope * base, "us_per_1000_fields": 1e3 * slope,
+                      "steady_state_frac_of_8TBs": bpf / (slope * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        out["batch_scaling"] = {"kernel_us": {str(k): v for k, v in pts.items()}, "fit": fit,
+                                "note": "kernel launch time (HIP events) at B/2, B, 2B fields; fit through the outer two"}
+    except Exception as e:
+        out["batch_scaling"] = {"error": repr(e)}
     # a complete adiabatic dynamical-core step (tendencies.f90:11-41 + time_stepping.f90:35-118 minus column physics) on
     # device-resident state, replayed as ONE graph: T30 L8 and BASELINE config 5 (T63 L16)
     for tag, res_, kx_ in (("dynamics_step_t30_l8", "t30", 8), ("dynamics_step_t63_l16", "t63", 16)):
@@ -629,11 +673,7 @@ def main():
 
     # synthetic white-noise grids: 64 seeded templates tiled and rescaled per field so
     # that every field of the batch is distinct; each rank owns its own shard of the batch index
-    uniq = 64
-    tmpl = torch.from_numpy(synth.grids(uniq, sp.ix, sp.il, first=rank * uniq)).to(dev)
-    reps = (nb + uniq - 1) // uniq
-    grid = tmpl.repeat(reps, 1, 1)[:nb].contiguous()
-    grid *= (1.0 + torch.arange(nb, dtype=torch.float64, device=dev).view(nb, 1, 1) / nb)
+    grid = headline_grids(torch, synth, sp, nb, rank, dev)
     spec = torch.zeros((nb, sp.nx, sp.mx), dtype=torch.complex128, device=dev)
     out = torch.zeros_like(grid)
 

@@ -144,3 +144,38 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
     sp.synchronize()
     assert torch.equal(big[:nb], a["plain"])
     sp.close()
+
+
+@pytest.mark.parametrize("tag,kx", [("t63", 8), ("t30", 8)])
+def test_write_through_policy_same_bits(tag, kx, monkeypatch):
+    """Model-sized launches with several MB of output store it write-through (sc0 sc1) instead of write-back (csrc: write_through_policy,
+    $SPDY_WT_MIN_MB): a cache policy, not arithmetic.  The by-chunk inverse launch, the grid tendencies and (T63) the staged direct
+    launch must give the same bits with the policy forced on for every launch (1 MB) and switched off (0)."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral(tag, kx=kx, max_batch=4 * kx + 4, device=0)
+    sp.initialize_implicit(2400.0)
+    dev = torch.device("cuda", 0)
+    nb = 4 * kx + 2
+    S = torch.from_numpy(synth.spectra(nb, sp.trunc, first=11, full_rows=True)).to(dev)
+    rng = np.random.default_rng(99)
+    px, py = (torch.from_numpy(rng.uniform(-1e-2, 1e-2, (1, sp.il, sp.ix))).to(dev) for _ in range(2))
+
+    def run():
+        f64 = lambda n: torch.full((n, sp.il, sp.ix), float("nan"), dtype=torch.float64, device=dev)
+        G, U, V, PL = f64(nb), f64(3 * kx), f64(3 * kx), f64(3 * kx + 1)
+        back = torch.full((3 * kx, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
+        sp.spec_to_grid_dev(S, G, kcos=1)
+        g = [G[i * kx:(i + 1) * kx] for i in range(4)]
+        sp.grid_tendencies_dev(g[0], g[1], g[2] + 250.0, g[3], g[0] * 1e-6, g[1].abs() * 1e-3, px, py, U, V, PL)
+        sp.grid_to_spec_dev(U, back)
+        sp.synchronize()
+        return G, U, V, PL, back
+    monkeypatch.setenv("SPDY_WT_MIN_MB", "1")
+    a = run()
+    monkeypatch.setenv("SPDY_WT_MIN_MB", "0")
+    b = run()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert not torch.isnan(x.real if x.is_complex() else x).any(), i
+        assert torch.equal(x, y), (tag, i)
+    sp.close()
