@@ -787,7 +787,8 @@ int spdy_grid_to_spec_dev(spdy_plan *p, int nb, const double *d_grid, double *d_
     if (nb && (!d_spec || !d_grid)) return fail(SPDY_ERR_ARG, "null device pointer");
     if (use_fused(p, nb))
         return timed(p, SPDY_K_G2S_FUSED, [&] {
-            return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu * p->wg_per_cu, p->stream);
+            return spdy::launch_g2s_fused(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu * p->wg_per_cu, p->stream, nullptr, nullptr, 0, nullptr,
+                                          nullptr, !in_host_stage(p, d_grid));
         });
     if (use_fused63(p, nb))
         return timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63(p->dev, nb, d_grid, nullptr, d_spec, p->num_cu, p->stream); });
@@ -1003,7 +1004,8 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
     const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
     if (use_fused(p, nb)) {
         // one pass: the pair (ug[i], vg[i]) is one tile, vds is applied to the two spectra while they are in LDS
-        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm));
+        KERNEL(spdy::launch_g2s_fused(p->dev, nb, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm, 0, nullptr, nullptr,
+                                      !in_host_stage(p, ug)));
         return SPDY_OK;
     }
     if (use_fused63_composite(p)) {             // both scaled transforms in ONE fused launch (two segments) + vds

@@ -108,6 +108,45 @@ def test_t30_small_batch_forms_agree(nb, monkeypatch):
     sp.close()
 
 
+@pytest.mark.parametrize("nb", [1, 2, 3, 25, 73, 127, 128, 129])
+def test_t30_small_direct_forms_agree(nb, monkeypatch):
+    """Small T30 direct launches (at most a quarter as many tiles as CUs: every model-shaped launch, every one-field call) run
+    with FOUR workgroups per tile -- all four do the tile's row FFTs, each contracts and stores a quarter of the zonal
+    wavenumbers (csrc/spdy_fused_t30.inc, NSPLIT).  Every coefficient is the same chain of matrix instructions either way: the
+    split form, the whole-tile form (SPDY_T30_NOSPLIT) and a large batch's persistent walk must agree BIT FOR BIT in every mode
+    of the kernel: plain fields, fields with a latitude factor, the vdspec pairs, a model step's mixed direct batch."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral("t30", kx=8, max_batch=2048, device=0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1234)
+    G = torch.from_numpy(rng.uniform(-0.5, 0.5, (2048, sp.il, sp.ix))).to(dev)
+    npair = max(1, min(nb // 3, 24))
+    c128 = lambda n: torch.full((n, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
+
+    def run():
+        out = {"plain": c128(nb), "vor": c128(npair), "div": c128(npair), "mvor": c128(npair), "mdiv": c128(npair), "mpl": c128(nb)}
+        sp.grid_to_spec_dev(G[:nb], out["plain"])
+        sp.vdspec_dev(G[:npair], G[npair:2 * npair], out["vor"], out["div"], 2)
+        sp.direct_batch_dev(G[:npair], G[npair:2 * npair], out["mvor"], out["mdiv"], G[100:100 + nb], out["mpl"], kcos=2)
+        sp.synchronize()
+        return out
+    monkeypatch.setenv("SPDY_T30_SPLIT_MIXED", "1")       # (the mixed batch keeps whole tiles by default: force its split form too)
+    a = run()
+    monkeypatch.setenv("SPDY_T30_NOSPLIT", "1")
+    b = run()
+    monkeypatch.delenv("SPDY_T30_NOSPLIT")
+    for k in a:
+        assert not torch.isnan(torch.view_as_real(a[k])).any(), k
+        assert torch.equal(a[k], b[k]), (nb, k)
+    # ... and inside a batch large enough for the persistent walk of the throughput form
+    big = c128(2048)
+    sp.grid_to_spec_dev(G, big)
+    sp.synchronize()
+    assert torch.equal(big[:nb], a["plain"])
+    sp.close()
+
+
 @pytest.mark.parametrize("nb", [1, 2, 9, 73, 146, 255])
 def test_t63_small_direct_forms_agree(nb, monkeypatch):
     """Small T63 direct batches (at most half as many pairs as CUs) run STAGED -- the row FFTs as a launch of their own over
