@@ -20,7 +20,10 @@ constexpr int MAXS = 38;                                     // slots per Legend
 constexpr int nmax(bool dir, int q) { return dir ? (TRUNC < TRUNC + 1 - 4 * q ? TRUNC : TRUNC + 1 - 4 * q) : TRUNC + 1 - 4 * q; }
 constexpr int ncount(bool dir, int q, int par) { return par == 0 ? nmax(dir, q) / 2 + 1 : (nmax(dir, q) + 1) / 2; }
 constexpr int ngrp(bool dir, int q, int par) { return (ncount(dir, q, par) + 3) / 4; }
-constexpr int wave_quad(int w, int i) { return i == 0 ? w : i == 1 ? 15 - w : i == 2 ? 4 + w : 11 - w; }
+// Quads of wave w at its four positions: {2w, 15-2w, 2w+1, 14-2w} -- equal work per wave (the quad indices add up to 30) and per
+// half (positions {0,1} / {2,3}: 15 each), and the two quads of positions (0, 2) and of (3, 1) are NEIGHBOURS (an even quad and
+// the next one), so that the direct kernel's write-out can store their coefficients as whole 128-byte lines (t63_dir_writeout).
+constexpr int wave_quad(int w, int i) { return i == 0 ? 2 * w : i == 1 ? 15 - 2 * w : i == 2 ? 2 * w + 1 : 14 - 2 * w; }
 // slot index of (quad position i, parity, n-group g) within wave w
 constexpr int slot_of(bool dir, int w, int i, int par, int g)
 {
