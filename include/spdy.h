@@ -73,8 +73,7 @@ enum {
  *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1     SPDY_T63_NOSPLIT     one workgroup per pair in small
  *   SPDY_T63_NOSTAGE   small T63 direct batches run fused (row FFTs inside the contraction launch) instead of staged (same bits)
  *   SPDY_T63_NP2_FROM  pairs from which the staged contraction takes two pairs per workgroup (default 40; same bits)
- *   SPDY_T30_NOSPLIT   small T30 direct batches as whole tiles instead of four workgroups per tile (same bits);
- *   SPDY_T30_SPLIT_MIXED  the split form also for a step's mixed direct batch (faster alone, not inside the captured step)
+ *   SPDY_T30_NOSPLIT   small T30 direct batches as whole tiles instead of three workgroups per tile (same bits)
  *   SPDY_WT_MIN_MB     output size (MB, default 6) from which a model-sized launch writes its output through the L2s instead of
  *                      leaving it dirty for the end-of-kernel release (0 = never; same bits either way)
  *   SPDY_COMM_TIMEOUT_S  seconds an in-process collective waits for its missing ranks before it breaks the group (default 120)

@@ -886,9 +886,9 @@ hipError_t prepare_device_kernels()
         {reinterpret_cast<const void *>(s2g_fused_t30_kernel<2, false, true>), t30::S2G_LDS}, {reinterpret_cast<const void *>(s2g_fused_t30_kernel<3, false, true>), t30::S2G_LDS},
         SPDY_K2(g2s_fused_t30_kernel, 0, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 1, t30::G2S_LDS),
         SPDY_K2(g2s_fused_t30_kernel, 2, t30::G2S_LDS), SPDY_K2(g2s_fused_t30_kernel, 3, t30::G2S_LDS),
-        // the four-workgroups-per-tile form of small direct batches (every model-sized T30 batch, the captured step)
-        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<0, false, 4>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<1, false, 4>), t30::G2S_LDS},
-        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<2, false, 4>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<3, false, 4>), t30::G2S_LDS},
+        // the three-workgroups-per-tile form of small direct batches (every model-sized T30 batch, the captured step)
+        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<0, false, 3>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<1, false, 3>), t30::G2S_LDS},
+        {reinterpret_cast<const void *>(g2s_fused_t30_kernel<2, false, 3>), t30::G2S_LDS}, {reinterpret_cast<const void *>(g2s_fused_t30_kernel<3, false, 3>), t30::G2S_LDS},
         SPDY_K2(g2s_fused_t63_kernel, 0, t63::LDS_BYTES), SPDY_K2(g2s_fused_t63_kernel, 1, t63::LDS_BYTES),
 #undef SPDY_K2
         {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, false>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(s2g_fused_t63_kernel<true, false>), t63::LDS_BYTES},

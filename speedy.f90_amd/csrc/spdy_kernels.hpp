@@ -89,7 +89,7 @@ hipError_t launch_s2g_fused(const DevPlan &p, int nb, const double *spec, const 
 hipError_t launch_g2s_fused(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg,
                             hipStream_t s, const double *grid2 = nullptr, double *spec2 = nullptr, int nplain = 0,
                             const double *grid_p = nullptr, double *spec_p = nullptr, bool allow_split = true);
-// (allow_split = false: never the four-workgroups-per-tile form -- its workgroups read every tile four times, which is the
+// (allow_split = false: never the three-workgroups-per-tile form -- its workgroups read every tile three times, which is the
 // wrong trade when the rows are host-mapped staging memory read across the link)
 
 // SIMD of each of the eight waves of nwg workgroups shaped like the fused T63 kernels' (d_out: 8 ints per workgroup)

@@ -111,7 +111,7 @@ def test_t30_small_batch_forms_agree(nb, monkeypatch):
 @pytest.mark.parametrize("nb", [1, 2, 3, 25, 73, 127, 128, 129])
 def test_t30_small_direct_forms_agree(nb, monkeypatch):
     """Small T30 direct launches (at most a quarter as many tiles as CUs: every model-shaped launch, every one-field call) run
-    with FOUR workgroups per tile -- all four do the tile's row FFTs, each contracts and stores a quarter of the zonal
+    with THREE workgroups per tile -- all three do the tile's row FFTs, each contracts and stores a third of the zonal
     wavenumbers (csrc/spdy_fused_t30.inc, NSPLIT).  Every coefficient is the same chain of matrix instructions either way: the
     split form, the whole-tile form (SPDY_T30_NOSPLIT) and a large batch's persistent walk must agree BIT FOR BIT in every mode
     of the kernel: plain fields, fields with a latitude factor, the vdspec pairs, a model step's mixed direct batch."""
@@ -131,7 +131,6 @@ def test_t30_small_direct_forms_agree(nb, monkeypatch):
         sp.direct_batch_dev(G[:npair], G[npair:2 * npair], out["mvor"], out["mdiv"], G[100:100 + nb], out["mpl"], kcos=2)
         sp.synchronize()
         return out
-    monkeypatch.setenv("SPDY_T30_SPLIT_MIXED", "1")       # (the mixed batch keeps whole tiles by default: force its split form too)
     a = run()
     monkeypatch.setenv("SPDY_T30_NOSPLIT", "1")
     b = run()

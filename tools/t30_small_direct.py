@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: what the split form of small T30 direct batches (four workgroups per tile, a quarter of the zonal wavenumbers each)
+"""GPU box: what the split form of small T30 direct batches (three workgroups per tile, a third of the zonal wavenumbers each)
 buys.  Graph-replay time per launch of model-shaped direct batches and of the captured T30 L8 step, default vs SPDY_T30_NOSPLIT=1."""
 import os
 import sys
@@ -33,7 +33,6 @@ def measure():
     return out
 
 
-os.environ["SPDY_T30_SPLIT_MIXED"] = "1"      # (the mixed batch and the step with the split form as well)
 a = measure()
 os.environ["SPDY_T30_NOSPLIT"] = "1"
 b = measure()
