@@ -15,15 +15,7 @@ __device__ __forceinline__ void st(double *a, long i, cpx z) { *reinterpret_cast
 // Write-through stores (sc0 sc1).  A kernel's ordinary stores stay dirty in the eight L2s until the end-of-kernel release
 // flushes them -- a serial tail of the launch that grows with the bytes written; written through they leave
 // as they are produced.  Worth it for outputs of several MB per launch; small outputs are better left to the write-back
-// cache.  (The 128-bit form is followed by two wait states: its data registers may be rewritten at once.)
-__device__ __forceinline__ void st_wt(double *a, long i, cpx z)
-{
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    d2v w;
-    w.x = z.re;
-    w.y = z.im;
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(a + 2 * i), "v"(w) : "memory");
-}
+// cache.
 __device__ __forceinline__ void st1_wt(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ cpx operator*(double r, cpx z) { return {r * z.re, r * z.im}; }
 __device__ __forceinline__ cpx operator+(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
