@@ -218,7 +218,7 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
     rob, wil, sdrag = float(np.float32(0.05)), float(np.float32(0.53)), 1.0 / (720.0 * 3600.0)
     sp.use_own_stream()
     torch.cuda.synchronize()
-    with sp.graph_capture() as g:
+    def one_step():
         # (the plain spectra are read in place from time level 2 of the four prognostic arrays: the graph is the whole step)
         sp.inverse_batch_segs_dev(D["vor"][1], D["div"][1], ug, vg, [D[n][1] for n in ("vor", "div", "t", "tr")], pg, D["ps"][1:2], px, py,
                                   kcos_pairs=2, kcos=1)
@@ -227,6 +227,8 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
         # leapfrog/RAW) as one call: two launches (at T63 vds is applied where the spectral step reads the pairs' spectra)
         sp.direct_batch_spectral_step_dev(U, V, PL, pvor, pdiv, pspec, D["vor"], D["div"], D["t"], D["tr"], D["ps"], phis, tcorh, qcorh,
                                           sdrag, 2, 2400.0, rob, wil, phi, kcos=2)
+    with sp.graph_capture() as g:
+        one_step()
     for _ in range(5):
         g.launch()
     sp.synchronize()
@@ -235,12 +237,25 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
         g.launch()
     sp.synchronize()
     us = (time.perf_counter() - t0) / reps * 1e6
+    g.close()
+    # the same step, EIGHT per graph (what the Fortran drop-in's steps_per_launch = 8 sends): a graph launch has a start-up
+    # latency of its own that back-to-back replays of a 34 us graph do not hide
+    with sp.graph_capture() as g8:
+        for _ in range(8):
+            one_step()
+    g8.launch()
+    sp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(1, reps // 4)):
+        g8.launch()
+    sp.synchronize()
+    us8 = (time.perf_counter() - t0) / (8 * max(1, reps // 4)) * 1e6
     finite = bool(torch.isfinite(torch.view_as_real(D["vor"])).all().item())
-    g.close(); sp.close()
+    g8.close(); sp.close()
     # timing of the captured step on synthetic state (nothing runs outside the graph between replays); parity of this exact
     # sequence, replayed twice, is tests/test_gpu_step.py::test_dynamical_core_step_graph
-    return {"us_per_step": us, "launches_in_graph": 4 if res == "t30" else 6, "transforms": 6 * kx + 2 + 9 * kx + 1, "levels": kx,
-            "state_finite_after_replays": finite}
+    return {"us_per_step": us, "us_per_step_eight_per_graph": us8, "launches_in_graph": 4 if res == "t30" else 6,
+            "transforms": 6 * kx + 2 + 9 * kx + 1, "levels": kx, "state_finite_after_replays": finite}
 
 
 def headline_grids(torch, synth, sp, nb, rank, dev):
@@ -447,7 +462,10 @@ def fortran_step_loop():
         f = o.stdout.split()
         if o.returncode != 0 or len(f) < 4:
             raise RuntimeError("rc %d: %s" % (o.returncode, (o.stdout + o.stderr)[-300:]))
-        return {"steps_per_s": float(f[0]), "us_per_step": round(1e6 / float(f[0]), 2), "steps": int(f[1]), "kx": int(f[3])}
+        r = {"steps_per_s": float(f[0]), "us_per_step": round(1e6 / float(f[0]), 2), "steps": int(f[1]), "kx": int(f[3])}
+        if len(f) >= 6:
+            r["state_checksum"] = f[5]                 # (of the final state: the same for every launch policy)
+        return r
     res = {}
     for tag in ("t30", "t63"):
         exe = os.path.join(ROOT, "speedy.f90_amd", "fortran", "build", tag, "dropin_step")
@@ -459,6 +477,12 @@ def fortran_step_loop():
         except Exception as e:
             res[tag] = {"error": repr(e)}
             continue
+        # deferred launches (time_stepping%steps_per_launch = 8 via $SPDY_STEPS_PER_LAUNCH): eight steps per graph launch
+        try:
+            res[tag]["eight_steps_per_launch"] = rate(exe, 2000, SPDY_STEPS_PER_LAUNCH="8")
+            res[tag]["eight_steps_per_launch"]["same_final_state"] = res[tag]["eight_steps_per_launch"].get("state_checksum") == res[tag].get("state_checksum")
+        except Exception as e:
+            res[tag]["eight_steps_per_launch"] = {"error": repr(e)}
         # the same loop as an UNMODIFIED host sees it: step() refreshes the host arrays of `prognostics` after every step
         # (time_stepping%host_refresh_interval = 1 via $SPDY_HOST_REFRESH: a 1.3 MB / 5.6 MB download + a sync per step)
         try:

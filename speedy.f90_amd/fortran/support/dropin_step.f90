@@ -38,7 +38,9 @@ program dropin_step
         call prognostics_from_device     ! waits for the queued steps (and brings the state back, as an output step would)
         call system_clock(c1)
         if (any(t /= t)) error stop 'dropin_step: the state did not stay finite'
-        write (*, '(F12.2,I8,3I5)') real(nleap, 8)*real(cr, 8)/real(c1 - c0, 8), nleap, trunc, kx, ntr
+        ! (the last field: a checksum of the final state -- the same for every $SPDY_STEPS_PER_LAUNCH)
+        write (*, '(F12.2,I8,3I5,ES26.17)') real(nleap, 8)*real(cr, 8)/real(c1 - c0, 8), nleap, trunc, kx, ntr, &
+            & sum(abs(real(t, 8))) + sum(abs(real(vor, 8))) + sum(abs(real(ps, 8))) + sum(abs(tr))
         call finalize_time_stepping
         call finalize_spectral
         return_now = .true.
@@ -77,6 +79,12 @@ contains
     subroutine isothermal_state
         vor = 0; div = 0; t = 0; tr = 0; ps = 0; phis = 0; tcorh = 0; qcorh = 0
         t(1,1,:,:) = 250.0_p*sqrt(2.0_p)
+        ! ... and a tracer pattern on it: a passive field (the winds stay zero), so the run stays finite for any length, but
+        ! diffusion changes it every step -- the checksum printed by the timing mode then tells a skipped or repeated step
+        ! from a correct run
+        tr(1,1,:,:,1) = 1.0e-2_p
+        tr(3,4,:,:,1) = (1.0e-3_p, 2.0e-3_p)
+        tr(7,12,:,:,1) = (-2.0e-3_p, 0.5e-3_p)
     end subroutine
 
     subroutine dump

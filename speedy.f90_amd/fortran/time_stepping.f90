@@ -38,7 +38,7 @@ module time_stepping
     public first_step, step
     ! extensions (not in the reference)
     public prognostics_to_device, prognostics_from_device, tendencies_from_device, finalize_time_stepping
-    public output_fields_from_device, host_refresh_interval
+    public output_fields_from_device, host_refresh_interval, steps_per_launch, flush_steps
 
     !> Coherent mode for an UNMODIFIED host.  The reference's main loop reads the host arrays of `prognostics` right after
     !  step() (speedy.f90:41 check_diagnostics, :44-50 output and the coupler); with the state in HBM those arrays go stale unless
@@ -49,6 +49,18 @@ module time_stepping
     !  variable SPDY_HOST_REFRESH sets the initial value, so that not even a recompile of the host is needed.
     integer :: host_refresh_interval = -1
     integer :: steps_since_refresh = 0
+
+    !> Deferred launches.  steps_per_launch = K > 1 lets step() collect K identical leapfrog steps and send them to the GPU as
+    !  ONE graph of K captured steps (the same kernels in the same order: the same bits), which takes the host's launch call
+    !  -- 2.8 of the 36.7 us a T30 L8 step costs from a Fortran main loop -- off all but every K-th step.  Whatever reads or
+    !  replaces the device state first launches what is pending (prognostics_from_device, output_fields_from_device,
+    !  tendencies_from_device, prognostics_to_device, a start-up step, a change of dt); a host that changes the model's
+    !  tables itself between two steps (initialize_implicit) calls flush_steps before.  Off (1) by default and whenever
+    !  host_refresh_interval is in use; the environment variable SPDY_STEPS_PER_LAUNCH sets the initial value.
+    integer :: steps_per_launch = -1
+    integer :: pending_steps = 0
+    type(c_ptr) :: graph_multi = c_null_ptr           ! steps_per_launch captured steps
+    integer :: graph_multi_steps = 0
 
     integer(c_size_t), parameter :: spec_bytes = 16_c_size_t*mx*nx, grid_bytes = 8_c_size_t*ix*il
 
@@ -90,8 +102,11 @@ contains
         real(p), intent(in) :: dt
         real(p) :: eps
 
+        integer :: i
+
         if (j1 < 1 .or. j1 > 2 .or. j2 < 1 .or. j2 > 2) error stop 'time_stepping%step: j1, j2 must be 1 or 2'
         if (.not. resident) call prognostics_to_device
+        call read_launch_policy
         if (j1 == 1) then
             eps = 0.0
         else
@@ -104,11 +119,15 @@ contains
         call enqueue_from_grid(j1, dt, eps)
 #else
         if (j1 /= 2) then                 ! the two start-up steps run once: plain launches
+            call flush_steps
             call enqueue_step(j1, j2, dt, eps)
         else
             if (c_associated(graph) .and. (graph_j1 /= j1 .or. graph_j2 /= j2 .or. graph_dt /= dt)) then
+                call flush_steps
                 call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
                 graph = c_null_ptr
+                if (c_associated(graph_multi)) call spdy_check(spdy_graph_destroy(graph_multi), 'graph_destroy')
+                graph_multi = c_null_ptr
             end if
             if (.not. c_associated(graph)) then
                 ! The implicit and damping tables are refreshed in place by initialize_implicit: the captured step sees them.
@@ -117,10 +136,51 @@ contains
                 call spdy_check(spdy_graph_end(spectral_plan, graph), 'graph_end')
                 graph_j1 = j1; graph_j2 = j2; graph_dt = dt
             end if
-            call spdy_check(spdy_graph_launch(graph), 'graph_launch')
+            if (steps_per_launch > 1 .and. host_refresh_interval <= 0) then
+                pending_steps = pending_steps + 1
+                if (pending_steps >= steps_per_launch) then
+                    if (c_associated(graph_multi) .and. graph_multi_steps /= steps_per_launch) then
+                        call spdy_check(spdy_graph_destroy(graph_multi), 'graph_destroy')
+                        graph_multi = c_null_ptr
+                    end if
+                    if (.not. c_associated(graph_multi)) then
+                        call spdy_check(spdy_graph_begin(spectral_plan), 'graph_begin')
+                        do i = 1, steps_per_launch
+                            call enqueue_step(j1, j2, dt, eps)
+                        end do
+                        call spdy_check(spdy_graph_end(spectral_plan, graph_multi), 'graph_end')
+                        graph_multi_steps = steps_per_launch
+                    end if
+                    call spdy_check(spdy_graph_launch(graph_multi), 'graph_launch')
+                    pending_steps = 0
+                end if
+            else
+                call spdy_check(spdy_graph_launch(graph), 'graph_launch')
+            end if
         end if
 #endif
         call refresh_host_if_due(j1)
+    end subroutine
+
+    !> Launch the leapfrog steps step() has collected but not sent yet (steps_per_launch), one by one.
+    subroutine flush_steps
+        integer :: i
+        do i = 1, pending_steps
+            call spdy_check(spdy_graph_launch(graph), 'graph_launch')
+        end do
+        pending_steps = 0
+    end subroutine
+
+    subroutine read_launch_policy
+        character(len=16) :: env
+        integer :: stat, n
+        if (steps_per_launch >= 0) return
+        steps_per_launch = 1
+        call get_environment_variable('SPDY_STEPS_PER_LAUNCH', env, status=stat)
+        if (stat == 0) then
+            read (env, *, iostat=stat) n
+            if (stat == 0 .and. n > 1) steps_per_launch = n
+        end if
     end subroutine
 
     !> host_refresh_interval (above): the host arrays follow the device state every N-th leapfrog step.
@@ -222,6 +282,7 @@ contains
         use horizontal_diffusion, only: tcorh, qcorh
 
         if (ntr /= 1) error stop 'time_stepping: the device step carries one tracer (ntr = 1, params.f90:26)'
+        call flush_steps                     ! (the pending steps belong to the state that is about to be replaced)
         call initialize_spectral
         if (.not. c_associated(d_vor)) then
             call alloc(d_vor, 2*kx*spec_bytes); call alloc(d_div, 2*kx*spec_bytes); call alloc(d_t, 2*kx*spec_bytes)
@@ -249,6 +310,7 @@ contains
         use prognostics, only: vor, div, t, ps, tr, phi
 
         if (.not. resident) return
+        call flush_steps
         call spdy_check(spdy_dev_download(spectral_plan, vor, d_vor, 2*kx*spec_bytes), 'download vor')
         call spdy_check(spdy_dev_download(spectral_plan, div, d_div, 2*kx*spec_bytes), 'download div')
         call spdy_check(spdy_dev_download(spectral_plan, t, d_t, 2*kx*spec_bytes), 'download t')
@@ -264,6 +326,7 @@ contains
         complex(p), intent(out) :: psdt(mx,nx), trdt(mx,nx,kx,ntr)
 
         if (.not. resident) error stop 'time_stepping%tendencies_from_device before the first step'
+        call flush_steps
         ! pvor = vordt | .. ; pdiv = divdt | tdt | trdt ; pspec(3 kx + 1) = psdt  (include/spdy.h, spdy_grid_tendencies_dev)
         call spdy_check(spdy_dev_download(spectral_plan, vordt, d_pvor, kx*spec_bytes), 'download vordt')
         call spdy_check(spdy_dev_download(spectral_plan, divdt, d_pdiv, kx*spec_bytes), 'download divdt')
@@ -283,6 +346,7 @@ contains
         integer(c_size_t), parameter :: fb = 4_c_size_t*ix*il
 
         if (.not. resident) error stop 'time_stepping%output_fields_from_device before the first step'
+        call flush_steps
         if (.not. c_associated(d_out)) then
             call alloc(d_out, (5*kx + 1)*fb)
             call spdy_check(spdy_output_workspace(spectral_plan), 'output_workspace')
@@ -300,8 +364,11 @@ contains
 
     !> Releases the captured step and the device state (before spectral%finalize_spectral).
     subroutine finalize_time_stepping
+        call flush_steps
         if (c_associated(graph)) call spdy_check(spdy_graph_destroy(graph), 'graph_destroy')
         graph = c_null_ptr
+        if (c_associated(graph_multi)) call spdy_check(spdy_graph_destroy(graph_multi), 'graph_destroy')
+        graph_multi = c_null_ptr
         call release(d_vor); call release(d_div); call release(d_t); call release(d_tr); call release(d_ps); call release(d_phi)
         call release(d_phis); call release(d_tcorh); call release(d_qcorh)
         call release(d_ug); call release(d_vg); call release(d_plain); call release(d_px); call release(d_py)
