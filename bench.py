@@ -473,16 +473,19 @@ def fortran_step_loop():
             res[tag] = {"error": "fortran/build/%s/dropin_step not built (flang absent at build time)" % tag}
             continue
         try:
-            res[tag] = dict(rate(exe, 2000), what="Fortran main loop: call step(2, 2, 2*delt) on device-resident prognostics (adiabatic core)")
+            res[tag] = dict(rate(exe, 2000), what="Fortran main loop: call step(2, 2, 2*delt) on device-resident prognostics (adiabatic core); "
+                                                   "plain launches (time_stepping%steps_per_launch = 0, the default)")
         except Exception as e:
             res[tag] = {"error": repr(e)}
             continue
-        # deferred launches (time_stepping%steps_per_launch = 8 via $SPDY_STEPS_PER_LAUNCH): eight steps per graph launch
-        try:
-            res[tag]["eight_steps_per_launch"] = rate(exe, 2000, SPDY_STEPS_PER_LAUNCH="8")
-            res[tag]["eight_steps_per_launch"]["same_final_state"] = res[tag]["eight_steps_per_launch"].get("state_checksum") == res[tag].get("state_checksum")
-        except Exception as e:
-            res[tag]["eight_steps_per_launch"] = {"error": repr(e)}
+        # the other launch policies ($SPDY_STEPS_PER_LAUNCH): the step as one captured graph launched once per step; eight
+        # steps per graph launch (deferred)
+        for key, k in (("one_graph_launch_per_step", "1"), ("eight_steps_per_graph_launch", "8")):
+            try:
+                res[tag][key] = rate(exe, 2000, SPDY_STEPS_PER_LAUNCH=k)
+                res[tag][key]["same_final_state"] = res[tag][key].get("state_checksum") == res[tag].get("state_checksum")
+            except Exception as e:
+                res[tag][key] = {"error": repr(e)}
         # the same loop as an UNMODIFIED host sees it: step() refreshes the host arrays of `prognostics` after every step
         # (time_stepping%host_refresh_interval = 1 via $SPDY_HOST_REFRESH: a 1.3 MB / 5.6 MB download + a sync per step)
         try:

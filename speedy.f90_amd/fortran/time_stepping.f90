@@ -10,8 +10,8 @@
 !      spdy_grid_tendencies_dev             the grid-space dynamical tendencies        tendencies.f90:105-197
 !      spdy_direct_batch_spectral_step_dev  direct transforms and all the rest         tendencies.f90:212-293, implicit.f90:168-217,
 !                                                                                      time_stepping.f90:62-167
-!  captured into one graph for the leapfrog step (j1 = j2 = 2) and replayed: 4 kernel launches at T30, 5 at T63, no host
-!  arithmetic, no PCIe traffic.  Results agree with the reference's call-by-call sequence to 1e-12
+!  4 kernel launches at T30, 6 at T63, no host arithmetic, no PCIe traffic -- issued as plain launches, or captured into a
+!  graph of one or several steps and replayed (steps_per_launch below).  Results agree with the reference's call-by-call sequence to 1e-12
 !  (tests/test_fortran_dropin.py, the time_stepping case).
 !
 !  With -DSPDY_WITH_PHYSICS the module is a drop-in for the FULL step(): between the grid-space dynamical tendencies and the
@@ -50,13 +50,17 @@ module time_stepping
     integer :: host_refresh_interval = -1
     integer :: steps_since_refresh = 0
 
-    !> Deferred launches.  steps_per_launch = K > 1 lets step() collect K identical leapfrog steps and send them to the GPU as
-    !  ONE graph of K captured steps (the same kernels in the same order: the same bits), which takes the host's launch call
-    !  -- 2.8 of the 36.7 us a T30 L8 step costs from a Fortran main loop -- off all but every K-th step.  Whatever reads or
-    !  replaces the device state first launches what is pending (prognostics_from_device, output_fields_from_device,
-    !  tendencies_from_device, prognostics_to_device, a start-up step, a change of dt); a host that changes the model's
-    !  tables itself between two steps (initialize_implicit) calls flush_steps before.  Off (1) by default and whenever
-    !  host_refresh_interval is in use; the environment variable SPDY_STEPS_PER_LAUNCH sets the initial value.
+    !> How the leapfrog steps reach the GPU.  steps_per_launch = 0 (default): plain launches, three calls (four or six kernels)
+    !  per step on the plan's stream -- the host thread runs ahead of the GPU and the kernels of consecutive steps follow each
+    !  other without a gap (T30 L8: 29.7 us per step, 33.7 k steps/s).  1: one captured graph of the step, launched once per
+    !  step -- a graph launch has a start-up latency of its own (4-7 us here) that back-to-back replays do not hide (36.7 us per
+    !  step), but the host thread issues one call per step instead of three.  K > 1: step() collects K identical leapfrog
+    !  steps and sends them as ONE graph of K captured steps (the same kernels in the same order: the same bits; 29.7 us per
+    !  step at K = 8 with an eighth of the launch calls) -- deferred: whatever reads or replaces the device state first launches
+    !  what is pending (prognostics_from_device, output_fields_from_device, tendencies_from_device, prognostics_to_device, a
+    !  start-up step, a change of dt); a host that changes the model's tables itself between two steps (initialize_implicit)
+    !  calls flush_steps before.  K > 1 is ignored while host_refresh_interval is in use.  The environment variable
+    !  SPDY_STEPS_PER_LAUNCH sets the initial value.
     integer :: steps_per_launch = -1
     integer :: pending_steps = 0
     type(c_ptr) :: graph_multi = c_null_ptr           ! steps_per_launch captured steps
@@ -118,7 +122,7 @@ contains
         call host_physics
         call enqueue_from_grid(j1, dt, eps)
 #else
-        if (j1 /= 2) then                 ! the two start-up steps run once: plain launches
+        if (j1 /= 2 .or. steps_per_launch == 0) then   ! the two start-up steps run once: plain launches (steps_per_launch = 0: every step)
             call flush_steps
             call enqueue_step(j1, j2, dt, eps)
         else
@@ -175,11 +179,11 @@ contains
         character(len=16) :: env
         integer :: stat, n
         if (steps_per_launch >= 0) return
-        steps_per_launch = 1
+        steps_per_launch = 0
         call get_environment_variable('SPDY_STEPS_PER_LAUNCH', env, status=stat)
         if (stat == 0) then
             read (env, *, iostat=stat) n
-            if (stat == 0 .and. n > 1) steps_per_launch = n
+            if (stat == 0 .and. n >= 0) steps_per_launch = n
         end if
     end subroutine
 

@@ -313,17 +313,18 @@ def test_sharded_step_from_one_fortran_process(tag, tmp_path, oracle_factory):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["t30", "t63"])
 def test_deferred_step_launches_same_state(tag):
-    """time_stepping%steps_per_launch ($SPDY_STEPS_PER_LAUNCH): K leapfrog steps leave as one graph of K captured steps instead
-    of K graph launches.  The same kernels in the same order: 50 steps from the same state must end in the same bits (the
-    driver prints a checksum of the final state) for K = 1, 4 (two steps left over for the flush) and 8."""
+    """time_stepping%steps_per_launch ($SPDY_STEPS_PER_LAUNCH): plain launches (0, the default), one captured graph per step (1),
+    or K leapfrog steps collected and sent as one graph of K captured steps.  The same kernels in the same order: 50 steps from
+    the same state must end in the same bits (the driver prints a checksum of the final state) for K = 0, 1, 4 (two steps
+    left over for the flush) and 8."""
     exe = os.path.join(FDIR, "build", tag, "dropin_step")
     if not os.path.exists(exe):
         pytest.skip("Fortran driver not built (no flang on this box and no prebuilt binary)")
     sums = {}
-    for k in ("1", "4", "8"):
+    for k in ("0", "1", "4", "8"):
         r = subprocess.run([exe, "time", "50"], capture_output=True, text=True, timeout=300, env=dict(os.environ, SPDY_STEPS_PER_LAUNCH=k))
         assert r.returncode == 0, r.stdout + r.stderr
         f = r.stdout.split()
         assert len(f) >= 6, r.stdout
         sums[k] = f[5]
-    assert sums["1"] == sums["4"] == sums["8"], sums
+    assert sums["0"] == sums["1"] == sums["4"] == sums["8"], sums
