@@ -108,9 +108,9 @@ def test_t30_small_batch_forms_agree(nb, monkeypatch):
     sp.close()
 
 
-@pytest.mark.parametrize("nb", [1, 2, 3, 25, 73, 127, 128, 129])
+@pytest.mark.parametrize("nb", [1, 2, 3, 25, 73, 83, 84, 85, 128])
 def test_t30_small_direct_forms_agree(nb, monkeypatch):
-    """Small T30 direct launches (at most a quarter as many tiles as CUs: every model-shaped launch, every one-field call) run
+    """Small T30 direct launches (at most a sixth as many tiles as CUs: the T30 L8 step's launch, every one-field call) run
     with THREE workgroups per tile -- all three do the tile's row FFTs, each contracts and stores a third of the zonal
     wavenumbers (csrc/spdy_fused_t30.inc, NSPLIT).  Every coefficient is the same chain of matrix instructions either way: the
     split form, the whole-tile form (SPDY_T30_NOSPLIT) and a large batch's persistent walk must agree BIT FOR BIT in every mode
