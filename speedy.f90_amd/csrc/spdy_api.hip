@@ -120,7 +120,7 @@ void build_packed_tables(const HostTables &t, int ks_inv, int js_dir, std::vecto
 // one double2 per lane and latitude chunk; 4x4x4 block = zonal wavenumber 4q+blk, A row = lane&3, k = lane>>4.
 //   direct : A[i = n row][k = lat]  = P(m,n,lat)*wt(lat),  .x/.y = the chunk's two k-steps of 4 latitudes
 //   inverse: A[i = lat][k = n]      = P(m,n,lat),          .x/.y = the chunk's two groups of 4 latitudes
-void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector<double> &inv)
+void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector<double> &inv, std::vector<double> &tri)
 {
     using namespace spdy::t63;
     const int mx = t.mx, nx = t.nx;
@@ -150,6 +150,13 @@ void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector
                                 }
                     }
         }
+    // the direct image by sub-chunk (one k-step of 4 latitudes: sub-chunk 2 c + h = chunk c, k-step h), two slots per double2
+    tri.assign((size_t)NLW * TSC * TS2 * 64 * 2, 0.0);
+    for (int w = 0; w < NLW; ++w)
+        for (int s = 0; s < nslots(true, w); ++s)
+            for (int sc = 0; sc < TSC; ++sc)
+                for (int lane = 0; lane < 64; ++lane)
+                    tri[((size_t)tri_frag(w, sc, s >> 1) * 64 + lane) * 2 + (s & 1)] = dir[((size_t)afrag(w, s, sc >> 1) * 64 + lane) * 2 + (sc & 1)];
 }
 
 int upload_all(spdy_plan *p)
@@ -224,12 +231,12 @@ int upload_all(spdy_plan *p)
                 }
         UP(is2g3, img_s2g3);
     }
-    d.img_g2s63 = d.img_s2g63 = nullptr;
+    d.img_g2s63 = d.img_s2g63 = d.img_g2s63t = nullptr;
     d.rows_ws = nullptr; d.rows_ws_fields = 0;
     if (t.trunc == 63) {
-        std::vector<double> i63d, i63i;
-        build_t63_images(t, i63d, i63i);
-        UP(i63d, img_g2s63); UP(i63i, img_s2g63);
+        std::vector<double> i63d, i63i, i63t;
+        build_t63_images(t, i63d, i63i, i63t);
+        UP(i63d, img_g2s63); UP(i63i, img_s2g63); UP(i63t, img_g2s63t);
         // row workspace of the staged small-batch direct transform (spdy_fused_t63.inc): a model step's direct batch is up to
         // three segments of at most max_batch fields, and the form only runs below one pair per two CUs -- model-shaped plans
         // get room for all of it (98 KB per field), throughput-sized plans for the 256 fields such a launch can have

@@ -26,6 +26,9 @@ struct DevPlan {
     const double *img_s2g3; // [3 parts][4 Legendre waves][10][64 lanes][2]
     // A-operand images of the fused T63 kernels: [4 Legendre waves][38 slots][6 chunks][64 lanes][2] (spdy_t63_sched.hpp)
     const double *img_g2s63, *img_s2g63;
+    // the direct image regrouped for the three-pairs-per-workgroup kernel (spdy_t63_tri.inc):
+    // [4 waves][12 sub-chunks of 4 latitudes][19 fragment pairs][64 lanes][2] = (slot 2 s2, slot 2 s2 + 1) of one k-step
+    const double *img_g2s63t;
     // row workspace of the staged form of small T63 direct batches: [pair][chunk][field][16 rows][128] Fourier rows
     double *rows_ws;
     int rows_ws_fields;     // capacity in fields (0: none -- the fused split form runs instead)

@@ -184,6 +184,44 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
     sp.close()
 
 
+@pytest.mark.parametrize("nb", [1, 2, 5, 6, 9, 96, 255])
+def test_t63_three_pair_direct_form_agrees(nb, monkeypatch):
+    """Throughput-sized T63 direct batches run THREE field pairs per workgroup, every Legendre operand fragment feeding three
+    matrix instructions (csrc/spdy_t63_tri.inc: one wave per SIMD, accumulators in AGPRs, rows landing by LDS-DMA).  Same row FFT
+    code, same chain of matrix instructions per coefficient: with the form forced on at every batch size (SPDY_T63_TRI=1) the
+    spectra must equal the pair-per-workgroup forms (SPDY_T63_TRI=0) BIT FOR BIT -- plain fields incl. ragged tiles (1, 2, 5
+    fields: duplicated pairs and an absent second field), the scaled pairs of vdspec and a three-segment direct batch."""
+    import torch
+    import speedy_f90_amd as s
+    sp = s.Spectral("t63", kx=8, max_batch=600, device=0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(977)
+    G = torch.from_numpy(rng.uniform(-0.5, 0.5, (600, sp.il, sp.ix))).to(dev)
+    npair = max(1, min(nb // 3, 48))
+    c128 = lambda n: torch.full((n, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
+
+    def run():
+        out = {"plain": c128(nb), "vor": c128(npair), "div": c128(npair), "mvor": c128(npair), "mdiv": c128(npair), "mpl": c128(nb)}
+        sp.grid_to_spec_dev(G[:nb], out["plain"])
+        sp.vdspec_dev(G[:npair], G[npair:2 * npair], out["vor"], out["div"], 2)
+        sp.direct_batch_dev(G[:npair], G[npair:2 * npair], out["mvor"], out["mdiv"], G[100:100 + nb], out["mpl"], kcos=2)
+        sp.synchronize()
+        return out
+    monkeypatch.setenv("SPDY_T63_TRI", "0")
+    a = run()
+    monkeypatch.setenv("SPDY_T63_TRI", "1")
+    b = run()
+    big = c128(600)
+    sp.grid_to_spec_dev(G, big)
+    sp.synchronize()
+    monkeypatch.delenv("SPDY_T63_TRI")
+    for k in a:
+        assert not torch.isnan(torch.view_as_real(b[k])).any(), k
+        assert torch.equal(a[k], b[k]), (nb, k, float((torch.view_as_real(a[k]) - torch.view_as_real(b[k])).abs().max()))
+    assert torch.equal(big[:nb], a["plain"])
+    sp.close()
+
+
 @pytest.mark.parametrize("tag,kx", [("t63", 8), ("t30", 8)])
 def test_write_through_policy_same_bits(tag, kx, monkeypatch):
     """Model-sized launches with several MB of output store it write-through (sc0 sc1) instead of write-back (csrc: write_through_policy,
