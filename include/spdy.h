@@ -70,16 +70,18 @@ enum {
 /* Environment read by the library (measurement and debugging aids; none changes results beyond rounding-level path choices):
  *   SPDY_DEVICE        device index for SPDY_DEVICE_AUTO              SPDY_FUSED = 0 | 1   initial spdy_plan_set_fused mode
  *   SPDY_WG_PER_CU     persistent workgroups per CU of the T30 kernels (default 1)
- *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1     SPDY_T63_NOSPLIT     one workgroup per pair in small
+ *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1
+ *   SPDY_T63_NOSPLIT   one workgroup per pair in small T63 direct launches instead of two (same bits)
+ *   SPDY_T63_TRI=1     T63 direct batches as three field pairs per workgroup (csrc/spdy_t63_tri.inc; same bits, slower: opt-in)
  *   SPDY_T63_NOSTAGE   small T63 direct batches run fused (row FFTs inside the contraction launch) instead of staged (same bits)
  *   SPDY_T63_NP2_FROM  pairs from which the staged contraction takes two pairs per workgroup (default 40; same bits)
  *   SPDY_T30_NOSPLIT   small T30 direct batches as whole tiles instead of three workgroups per tile (same bits)
  *   SPDY_WT_MIN_MB     output size (MB, default 6) from which a model-sized launch writes its output through the L2s instead of
  *                      leaving it dirty for the end-of-kernel release (0 = never; same bits either way)
- *   SPDY_COMM_TIMEOUT_S  seconds an in-process collective waits for its missing ranks before it breaks the group (default 120)
+ *   SPDY_COMM_TIMEOUT_S  seconds (> 0, read once; default 120) an in-process collective waits for its missing ranks before it breaks the group
  *   SPDY_T30_NOPART    small T30 inverse launches walk whole tiles instead of (tile, third of the latitudes) items (same bits)
- *   SPDY_COMM_DRY=1    RCCL communicators created under it skip their                      T63 direct launches (same bits)
- *                      collectives (timing a sharded step without its exchanges; results are then wrong)
+ *   SPDY_COMM_DRY=1    RCCL communicators created under it skip their collectives (timing a sharded step without its
+ *                      exchanges; results are then wrong)
  *   SPDY_HOST_STAGE_KB host-pointer calls whose largest array is at most this many KB (default 512; 0 = never) stage through
  *                      pinned host memory mapped into the device: the caller's thread copies in and out, the kernels read and
  *                      write the staging buffers across the link themselves (no copy-engine round trips: 1.4-1.6x the rate

@@ -147,10 +147,14 @@ int group_barrier(spdy_comm_group *g)
         g->cv.notify_all();
         return SPDY_OK;
     }
-    double limit = 120.0;
-    if (const char *env = getenv("SPDY_COMM_TIMEOUT_S")) limit = atof(env);
+    static const double limit = [] {                         // parsed once; a value that is not a positive number keeps the default
+        const char *env = getenv("SPDY_COMM_TIMEOUT_S");
+        const double v = env ? atof(env) : 0.0;
+        return v > 0.0 ? v : 120.0;
+    }();
     if (!g->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return g->generation != gen || g->broken; })) {
         g->broken = true;
+        g->arrived = 0;
         g->cv.notify_all();
         return fail(SPDY_ERR_COMM, "in-process collective: %d of %d ranks arrived within %.0f s (each rank must call from its own thread)",
                     g->arrived, g->nranks, limit);
@@ -163,6 +167,22 @@ int group_barrier(spdy_comm_group *g)
  * rank has filled block `rank` of every array, afterwards every rank holds all blocks.  RCCL: ONE grouped operation on the
  * plan's stream (graph-capturable) -- equal, densely packed blocks: one in-place ncclAllGather per array (each rank's block
  * travels over its own xGMI link); anything else: one ncclBroadcast per rank and array.                              */
+void group_break(spdy_comm_group *g)
+{
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->broken = true;
+    g->cv.notify_all();
+}
+// (inside an in-process collective: a HIP error on this rank must not leave the peers waiting at the next barrier)
+#define HIP_TRY_GROUP(g_, expr)                                                                            \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            group_break(g_);                                                                               \
+            return fail(SPDY_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                      \
+        }                                                                                                  \
+    } while (0)
+
 int allgather_blocks(spdy_comm *c, int narr, double *const *d, const size_t *off, const size_t *cnt)
 {
     spdy_plan *p = c->plan;
@@ -171,22 +191,24 @@ int allgather_blocks(spdy_comm *c, int narr, double *const *d, const size_t *off
         spdy_comm_group *g = c->grp;
         NOT_CAPTURING(p, "a collective of an in-process communicator (peer copies ordered by events of other ranks' streams)");
         for (int a = 0; a < narr; ++a) g->arr[a][c->rank] = d[a];
-        HIP_TRY(hipEventRecord(g->ready[c->rank], p->stream));
+        HIP_TRY_GROUP(g, hipEventRecord(g->ready[c->rank], p->stream));
         RC(group_barrier(g));
         for (int q = 0; q < c->nranks; ++q) {
             if (q == c->rank || cnt[q] == 0) continue;
-            HIP_TRY(hipStreamWaitEvent(p->stream, g->ready[q], 0));
+            HIP_TRY_GROUP(g, hipStreamWaitEvent(p->stream, g->ready[q], 0));
             for (int a = 0; a < narr; ++a) {
                 if (g->device[q] == p->device)
-                    HIP_TRY(hipMemcpyAsync(d[a] + off[q], g->arr[a][q] + off[q], cnt[q] * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+                    HIP_TRY_GROUP(g, hipMemcpyAsync(d[a] + off[q], g->arr[a][q] + off[q], cnt[q] * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
                 else
-                    HIP_TRY(hipMemcpyPeerAsync(d[a] + off[q], p->device, g->arr[a][q] + off[q], g->device[q], cnt[q] * sizeof(double), p->stream));
+                    HIP_TRY_GROUP(g, hipMemcpyPeerAsync(d[a] + off[q], p->device, g->arr[a][q] + off[q], g->device[q], cnt[q] * sizeof(double), p->stream));
             }
         }
-        HIP_TRY(hipEventRecord(g->done[c->rank], p->stream));
+        HIP_TRY_GROUP(g, hipEventRecord(g->done[c->rank], p->stream));
         RC(group_barrier(g));
+        // (the events belong to the GROUP and live until spdy_comm_group_destroy: a peer that has already finished its step and
+        // destroyed its communicator cannot pull done[q] away from under this wait)
         for (int q = 0; q < c->nranks; ++q)
-            if (q != c->rank) HIP_TRY(hipStreamWaitEvent(p->stream, g->done[q], 0));
+            if (q != c->rank) HIP_TRY_GROUP(g, hipStreamWaitEvent(p->stream, g->done[q], 0));
         return SPDY_OK;
     }
     if (c->nranks == 1 && !c->force) return SPDY_OK;
@@ -267,6 +289,11 @@ int spdy_comm_group_destroy(spdy_comm_group *g)
         std::lock_guard<std::mutex> lk(g->mu);
         if (g->attached) return fail(SPDY_ERR_STATE, "%d communicators of the group are still alive", g->attached);
     }
+    for (int q = 0; q < g->nranks; ++q) {                    // the ranks' events: created on first attach, owned by the group
+        if (g->device[q] >= 0) (void)hipSetDevice(g->device[q]);
+        if (g->ready[q]) (void)hipEventDestroy(g->ready[q]);
+        if (g->done[q]) (void)hipEventDestroy(g->done[q]);
+    }
     delete g;
     return SPDY_OK;
 }
@@ -278,22 +305,43 @@ int spdy_comm_create_local(spdy_plan *p, spdy_comm_group *g, int rank, spdy_comm
     *comm = nullptr;
     if (!g || rank < 0 || rank >= g->nranks) return fail(SPDY_ERR_ARG, "null group / rank %d outside it", rank);
     NOT_CAPTURING(p, "spdy_comm_create_local");
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     std::lock_guard<std::mutex> lk(g->mu);
-    if (g->member[rank]) {
-        for (auto &e : ev) (void)hipEventDestroy(e);
-        return fail(SPDY_ERR_STATE, "rank %d of the group already exists", rank);
+    if (g->member[rank]) return fail(SPDY_ERR_STATE, "rank %d of the group already exists", rank);
+    if (g->ready[rank] && g->device[rank] != p->device) {       // the slot's events were made on another device: start afresh
+        (void)hipSetDevice(g->device[rank]);
+        (void)hipEventDestroy(g->ready[rank]); (void)hipEventDestroy(g->done[rank]);
+        g->ready[rank] = g->done[rank] = nullptr;
+        (void)hipSetDevice(p->device);
+    }
+    if (!g->ready[rank]) {
+        // The events are the GROUP's (destroyed with it, not with the communicator): after the second barrier of a collective a
+        // peer still issues hipStreamWaitEvent on done[rank] while this rank may already be tearing its communicator down.
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (auto &e : ev) {
+            const hipError_t er = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (er != hipSuccess) {
+                if (ev[0]) (void)hipEventDestroy(ev[0]);
+                return fail(SPDY_ERR_HIP, "hipEventCreateWithFlags failed: %s", hipGetErrorString(er));
+            }
+        }
+        g->ready[rank] = ev[0]; g->done[rank] = ev[1];
     }
     for (int q = 0; q < g->nranks; ++q)
-        if (g->member[q] && g->device[q] != p->device) {        // peers on other devices: let the copy engines reach them
+        if (g->member[q] && g->device[q] != p->device) {        // peers on other devices: let the copy engines reach them, BOTH ways
             int can = 0;
             (void)hipDeviceCanAccessPeer(&can, p->device, g->device[q]);
             if (can) { (void)hipDeviceEnablePeerAccess(g->device[q], 0); (void)hipGetLastError(); }
+            can = 0;
+            (void)hipDeviceCanAccessPeer(&can, g->device[q], p->device);
+            if (can) {                                          // (an earlier rank pulls from this one as well)
+                (void)hipSetDevice(g->device[q]);
+                (void)hipDeviceEnablePeerAccess(p->device, 0); (void)hipGetLastError();
+                (void)hipSetDevice(p->device);
+            }
         }
     spdy_comm *c = new spdy_comm;
     c->plan = p; c->grp = g; c->nranks = g->nranks; c->rank = rank;
-    g->member[rank] = c; g->ready[rank] = ev[0]; g->done[rank] = ev[1]; g->device[rank] = p->device;
+    g->member[rank] = c; g->device[rank] = p->device;
     ++g->attached;
     p->comms.push_back(c);
     *comm = c;
@@ -312,10 +360,8 @@ int spdy_comm_destroy(spdy_comm *c)
     }
     if (spdy_comm_group *g = c->grp) {
         std::lock_guard<std::mutex> lk(g->mu);
-        if (g->member[c->rank] == c) {
+        if (g->member[c->rank] == c) {                          // (its events stay with the group: peers may still wait on them)
             g->member[c->rank] = nullptr;
-            (void)hipEventDestroy(g->ready[c->rank]); (void)hipEventDestroy(g->done[c->rank]);
-            g->ready[c->rank] = g->done[c->rank] = nullptr;
             --g->attached;
         }
     }

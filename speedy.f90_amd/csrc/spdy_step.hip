@@ -92,9 +92,6 @@ constexpr size_t spectral_step_lds_max() { return spectral_step_lds(16); }
 constexpr int GT_BX = 16;            // grid points per block of the grid-tendencies kernel
 constexpr size_t grid_tendencies_lds(int kx, int bx = GT_BX) { return ((size_t)(6 * kx + 2 * (kx + 1) + 3) * bx + kx) * sizeof(double); }
 constexpr int STEP_BX = 16;          // coefficients per block of the one-launch spectral step
-template <int NJ, bool FULL>
-__global__ void spectral_step_kernel(DevPlan p, SpecStep a);
-
 hipError_t prepare_device_step_kernels(int kx)
 {
     static_assert(grid_tendencies_lds(16) <= 64 * 1024, "the grid-tendencies kernel fits the default dynamic LDS limit");

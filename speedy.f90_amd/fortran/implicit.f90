@@ -25,6 +25,7 @@ contains
     subroutine initialize_implicit(dt)
         use horizontal_diffusion, only: dmp1, dmp1d, dmp1s
         real(p), intent(in) :: dt
+        call spdy_flush_pending()    ! leapfrog steps time_stepping has collected but not launched yet belong to the OLD tables
         call spdy_check(spdy_implicit_init(spectral_plan, real(dt, c_double)), 'initialize_implicit')
         call spdy_check(spdy_get_table(spectral_plan, 'dmp1'//c_null_char, dmp1, int(mx*nx, c_int)), 'dmp1')
         call spdy_check(spdy_get_table(spectral_plan, 'dmp1d'//c_null_char, dmp1d, int(mx*nx, c_int)), 'dmp1d')

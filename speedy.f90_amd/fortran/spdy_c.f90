@@ -608,7 +608,20 @@ module spdy_c
 
     integer(c_int), parameter :: SPDY_DEVICE_AUTO = -2_c_int   !! $SPDY_DEVICE, else the launcher's local rank (include/spdy.h)
 
+    !> Work a drop-in module has deferred on the device and that must be issued before the plan's tables change (time_stepping's
+    !  collected leapfrog steps under steps_per_launch > 1): the module registers its flush routine here, and every wrapper that
+    !  re-uploads tables (implicit%initialize_implicit) calls spdy_flush_pending first -- no circular module dependency.
+    abstract interface
+        subroutine spdy_flush_iface()
+        end subroutine
+    end interface
+    procedure(spdy_flush_iface), pointer, save :: spdy_pending_flush => null()
+
 contains
+    subroutine spdy_flush_pending()
+        if (associated(spdy_pending_flush)) call spdy_pending_flush()
+    end subroutine
+
     !> The reference has no status returns (it `stop`s on fatal errors, e.g. matrix_inversion.f90:26);
     !  the drop-in keeps the signatures and turns a non-zero C status into `error stop`.
     subroutine spdy_check(rc, what)

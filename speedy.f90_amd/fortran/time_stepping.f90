@@ -63,6 +63,7 @@ module time_stepping
     !  SPDY_STEPS_PER_LAUNCH sets the initial value.
     integer :: steps_per_launch = -1
     integer :: pending_steps = 0
+    integer :: pending_under = 0                      ! the steps_per_launch value the pending steps were collected under
     type(c_ptr) :: graph_multi = c_null_ptr           ! steps_per_launch captured steps
     integer :: graph_multi_steps = 0
 
@@ -140,7 +141,11 @@ contains
                 call spdy_check(spdy_graph_end(spectral_plan, graph), 'graph_end')
                 graph_j1 = j1; graph_j2 = j2; graph_dt = dt
             end if
+            ! a host that changes steps_per_launch between steps: what was collected under the old value goes out first, in order
+            if (pending_steps > 0 .and. steps_per_launch /= pending_under) call flush_steps
             if (steps_per_launch > 1 .and. host_refresh_interval <= 0) then
+                spdy_pending_flush => flush_steps      ! (table re-uploads of the other drop-in modules flush through this hook)
+                pending_under = steps_per_launch
                 pending_steps = pending_steps + 1
                 if (pending_steps >= steps_per_launch) then
                     if (c_associated(graph_multi) .and. graph_multi_steps /= steps_per_launch) then

@@ -381,11 +381,12 @@ def _rccl_rank(rank, world, port, tag, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tag", [(2, "t30"), (3, "t30"), (2, "t63k16")])
+@pytest.mark.parametrize("world,tag", [(2, "t30"), (3, "t30"), (2, "t63k16"), (4, "t30"), (8, "t30"), (4, "t63k16"), (8, "t63k16")])
 def test_sharded_step_rccl_ranks(world, tag):
     """BASELINE config 3 on real RCCL ranks (one process per GPU): every rank captures the complete sharded step -- its two
     all-gathers included -- into a graph, replays it twice from NaN-poisoned exchange stacks and must hold the oracle's
-    prognostics.  world 3 with 8 levels: ragged blocks -> grouped ncclBroadcast.  Skipped on boxes with fewer GPUs."""
+    prognostics.  world 3 with 8 levels: ragged blocks -> grouped ncclBroadcast; world 8 at T30 L8 is config 3's own rank
+    count (one level per rank), world 8 at T63 L16 two levels per rank.  Skipped on boxes with fewer GPUs."""
     import torch
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))

@@ -127,10 +127,11 @@ def _two_rank_worker(rank, world, port, kx, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kx", [(2, 8), (3, 8)])
+@pytest.mark.parametrize("world,kx", [(2, 8), (3, 8), (4, 8), (8, 8)])
 def test_multi_rank_sharded_implicit(world, kx):
     """BASELINE config 3 on real ranks: each rank fills its own level block, spdy_implicit_terms_sharded_dev completes the
-    stacks over RCCL (world 2: in-place ncclAllGather; world 3 with 8 levels: ragged blocks -> grouped ncclBroadcast) and
+    stacks over RCCL (world 2, 4, 8: in-place ncclAllGather -- 8 is config 3's own rank count, one level per rank; world 3 with 8
+    levels: ragged blocks -> grouped ncclBroadcast) and
     every rank must hold the oracle's result.  Skipped on boxes with fewer GPUs."""
     import torch
     if torch.cuda.device_count() < world:
