@@ -317,9 +317,22 @@ def extras(s, torch, synth, sp, dev, args):
     def rt_in_place():
         sp.grid_to_spec_dev(gi, si)
         sp.spec_to_grid_dev(si, gi, kcos=1)
-    us = _time_us(torch, sp, rt_in_place, reps=50, warm=10)
-    out["round_trip_in_place"] = {"fields": nbi, "round_trips_per_s": nbi / (us * 1e-6), "us_per_step": us}
-    del gi, si
+    # Timed like `value` (replays of one captured graph on the plan's stream).  Until round 4 this figure came from eager ctypes
+    # launches on torch's legacy default stream (`eager_default_stream_round_trips_per_s`, kept beside it): that stream's implicit
+    # synchronisation costs ~10 us per step once the kernels are this short, which is what BENCH_r04's "-5 %" was -- the kernels
+    # themselves run in place as fast as with separate buffers (tools/inplace_ab.py, same-box A/B of the store policies).
+    us_eager = _time_us(torch, sp, rt_in_place, reps=50, warm=10)
+    us = _time_graph_us(sp, rt_in_place, per_graph=20, reps=5, warm=2)
+    go = torch.zeros_like(gi)
+    us_sep = _time_graph_us(sp, lambda: (sp.grid_to_spec_dev(gi, si), sp.spec_to_grid_dev(si, go, kcos=1)), per_graph=20, reps=5, warm=2)
+    out["round_trip_in_place"] = {"fields": nbi, "round_trips_per_s": nbi / (us * 1e-6), "us_per_step": us,
+                                  "separate_buffers_same_method_round_trips_per_s": nbi / (us_sep * 1e-6),
+                                  "eager_default_stream_round_trips_per_s": nbi / (us_eager * 1e-6),
+                                  "method": "graph replay of 20 steps on the plan's stream, wall clock (as `value`)"}
+    # regression guards: figures that slipped once without anyone noticing
+    out["regressions"] = [{"what": "round trip written back in place vs separate buffers (same method, same run)",
+                           "value": us_sep / us, "floor": 0.95, "ok": bool(us_sep / us >= 0.95)}]
+    del gi, si, go
     # How a launch's time splits into a fixed part (launch boundary, pipeline fill and drain) and a per-field part: the same two
     # kernels at half and at twice the metric's batch.  The slope is the kernels' steady-state rate, what `roofline.frac`
     # would be without the fixed part at B = 6144 (T30) / 1536 (T63).
@@ -500,6 +513,23 @@ def fortran_step_loop():
             except Exception as e:
                 res[tag]["with_host_physics_hook"] = {"error": repr(e)}
     return res
+
+
+def collect_errors(node, path=""):
+    """Paths of every {"error": ...} entry below `node` (the side measurements never break the headline line; they must not
+    fail silently either)."""
+    found = []
+    if isinstance(node, dict):
+        for k, v in node.items():
+            here = "%s.%s" % (path, k) if path else str(k)
+            if k == "error":
+                found.append({"where": path or "<top>", "error": str(v)[:300]})
+            else:
+                found.extend(collect_errors(v, here))
+    elif isinstance(node, (list, tuple)):
+        for i, v in enumerate(node):
+            found.extend(collect_errors(v, "%s[%d]" % (path, i)))
+    return found
 
 
 def _free_port():
@@ -815,7 +845,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": dom_ms, "bytes_per_launch": ab[dom] * nb,
                          "mfma_util": mfma_util, "mfma_util_source": mfma_source,
-                         "all_kernels_ms": kinds},
+                         "all_kernels_ms": kinds,
+                         "launch_ms_method": "HIP events around each kernel on the launch stream, %d EAGER steps outside the timed region; "
+                                             "the timed blocks replay one graph of the K steps, so sum(all_kernels_ms) exceeds ms_per_step "
+                                             "by the event overhead (a few %%): `frac` is on the conservative side" % prof_steps},
         }
     # N > 1 (every rank takes part; never fatal, never inside `value`): what a level-sharded step adds
     if (world > 1 and not args.no_multi and args.res == "t30") or args.force_multi:
@@ -840,6 +873,7 @@ def main():
                 res["cpu_baseline_fast_math"] = fast
             res["cpu_baseline_socket"] = cpu_baseline_socket(args.res, "fast" if fast else "")
             res["gpu_over_cpu_socket"] = value / res["cpu_baseline_socket"]["value"]
+        res["errors"] = collect_errors(res)          # every side measurement that failed, by path: none is hidden in a nested string
         print(json.dumps(res))
     sp.close()
     if dist:

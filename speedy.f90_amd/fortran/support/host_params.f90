@@ -17,7 +17,11 @@ module params
     integer, parameter :: trunc = 30, ix = 96, iy = 24
 #endif
     integer, parameter :: il = 2*iy, kx = 8, nx = trunc + 2, mx = trunc + 1
+#ifdef SPDY_NSTEPS
+    integer, parameter :: nsteps = SPDY_NSTEPS  ! (experiments: another step length)
+#else
     integer, parameter :: nsteps = 36          ! params.f90:30 (read by initialize_horizontal_diffusion)
+#endif
     ! read by time_stepping (params.f90:26, :31-33); default-real literals, as the model writes them
     integer, parameter :: ntr = 1
     real(real64), parameter :: delt = real(86400.0/nsteps, real64), rob = real(0.05, real64), wil = real(0.53, real64)

@@ -20,7 +20,8 @@ contains
         pslg = spec_to_grid(psl, 1)
         do k = 1, kx
             g = spec_to_grid(phi(:,:,k), 1)
-            utend(:,:,k) = utend(:,:,k) + 1.0e-9_p*g                    ! a "drag" built from the geopotential
+            utend(:,:,k) = utend(:,:,k) + 1.0e-12_p*g                   ! a "push" built from the geopotential (1e-9 until round 5:
+                                                                        ! 0.5 m/s per step on the timing loop's state)
             g = spec_to_grid(vor(:,:,k), 1)
             vtend(:,:,k) = 0.999_p*vtend(:,:,k) + 1.0e-3_p*g
             g = spec_to_grid(t(:,:,k), 1)

@@ -159,7 +159,7 @@ def standin_physics(o, st, utend, vtend, ttend, trtend):
     phi = o.geopotential(st["t"][0], st["phis"])
     pslg = o.spec_to_grid(st["ps"][0], 1)
     for k in range(o.kx):
-        utend[k] = utend[k] + 1.0e-9 * o.spec_to_grid(phi[k], 1)
+        utend[k] = utend[k] + 1.0e-12 * o.spec_to_grid(phi[k], 1)
         vtend[k] = 0.999 * vtend[k] + 1.0e-3 * o.spec_to_grid(st["vor"][0, k], 1)
         ttend[k] = ttend[k] - 1.0e-6 * (o.spec_to_grid(st["t"][0, k], 1) - 250.0)
         g = o.spec_to_grid(st["tr"][0, k], 1) + o.spec_to_grid(st["div"][0, k], 1)
