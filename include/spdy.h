@@ -82,6 +82,9 @@ enum {
  *   SPDY_T30_NOPART    small T30 inverse launches walk whole tiles instead of (tile, third of the latitudes) items (same bits)
  *   SPDY_COMM_DRY=1    RCCL communicators created under it skip their collectives (timing a sharded step without its
  *                      exchanges; results are then wrong)
+ *   SPDY_HOST_SPIN=0   host-staged calls (below) end in hipStreamSynchronize instead of spinning on a host-mapped completion stamp that
+ *                      a one-thread kernel behind the call's kernels writes (the spin saves the runtime's wake-up: 1.3x the rate of
+ *                      one-field calls at T30; it gives up after 2 s and falls back to the runtime)
  *   SPDY_HOST_STAGE_KB host-pointer calls whose largest array is at most this many KB (default 512; 0 = never) stage through
  *                      pinned host memory mapped into the device: the caller's thread copies in and out, the kernels read and
  *                      write the staging buffers across the link themselves (no copy-engine round trips: 1.4-1.6x the rate

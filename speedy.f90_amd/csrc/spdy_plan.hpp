@@ -35,6 +35,8 @@ struct spdy_plan {
     double *dstage[4] = {nullptr, nullptr, nullptr, nullptr};   // device memory, max_batch grids each
     double *hstage[4] = {nullptr, nullptr, nullptr, nullptr};   // hipHostMalloc (mapped, coherent), hstage_elems doubles each
     int *h_kcos = nullptr;                                      // hstage-route twin of d_kcos
+    unsigned *h_stamp = nullptr;                                // host-mapped completion stamp of the hstage route (sync())
+    unsigned stamp_seq = 0;
     size_t hstage_elems = 0;
     struct Pending { void *dst; const void *src; size_t bytes; };
     std::vector<Pending> pending;     // device-written host-stage results still to be copied to the caller's arrays
