@@ -163,3 +163,16 @@ def test_no_store_data_hazard_in_isa():
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
 
+
+
+def test_bench_collects_errors_of_side_measurements():
+    """bench.py lists every failed side measurement by path in a top-level `errors` entry (round 4's driver run carried a nested
+    RuntimeError string nobody saw)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    res = {"value": 1.0, "extras": {"a": {"error": "RuntimeError('x')"}, "b": [{"ok": 1}, {"error": "y"}], "c": {"fine": True}}, "errors": []}
+    got = bench.collect_errors(res)
+    assert [e["where"] for e in got] == ["extras.a", "extras.b[1]"]
+    assert bench.collect_errors({"extras": {"c": {"fine": True}}}) == []
