@@ -93,7 +93,7 @@ def _step_worker(rank, world, port, kx, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kx", [(2, 8), (3, 8)])
+@pytest.mark.parametrize("world,kx", [(2, 8), (3, 8), (8, 8)])      # 8 ranks x 8 levels: BASELINE config 3's own shape, one level per rank
 def test_multi_rank_sharded_step(world, kx, tmp_path):
     """The COMPLETE level-sharded adiabatic step (speedy_f90_amd.sharding.sharded_step_host: the data flow of
     spdy_sharded_step_dev with the oracle as the executor of the single procedures) over gloo: each rank transforms only its own
