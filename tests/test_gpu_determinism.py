@@ -219,6 +219,19 @@ def test_t63_three_pair_direct_form_agrees(nb, monkeypatch):
         assert not torch.isnan(torch.view_as_real(b[k])).any(), k
         assert torch.equal(a[k], b[k]), (nb, k, float((torch.view_as_real(a[k]) - torch.view_as_real(b[k])).abs().max()))
     assert torch.equal(big[:nb], a["plain"])
+    if nb == 255:
+        # ... and the scaled rows (vdspec's cos-latitude factor) in the STREAMING instantiation: 2 x 150 fields = 44 MB of grids
+        def scaled():
+            v, d = c128(150), c128(150)
+            sp.vdspec_dev(G[:150], G[150:300], v, d, 2)
+            sp.synchronize()
+            return v, d
+        monkeypatch.setenv("SPDY_T63_TRI", "0")
+        v0, d0 = scaled()
+        monkeypatch.setenv("SPDY_T63_TRI", "1")
+        v1, d1 = scaled()
+        monkeypatch.delenv("SPDY_T63_TRI")
+        assert torch.equal(v0, v1) and torch.equal(d0, d1)
     sp.close()
 
 
