@@ -67,18 +67,21 @@ enum {
  * inside an open capture is refused with SPDY_ERR_STATE).  Destroying a plan also invalidates the graphs captured
  * from it (spdy_graph_launch then returns SPDY_ERR_STATE) and shuts down its communicators (spdy_comm_*: the handles
  * stay valid for spdy_comm_destroy, every other call on them returns SPDY_ERR_STATE).                              */
-/* Environment read by the library (measurement and debugging aids; none changes results beyond rounding-level path choices):
+/* Environment read by the library (measurement and debugging aids; none changes results beyond rounding-level path choices).
+ * The launch-policy switches (SPDY_T30_*, SPDY_T63_*, SPDY_WT_MIN_MB) are read ONCE per plan, in spdy_plan_create; a plan's
+ * values are changed afterwards with spdy_plan_set_option.
  *   SPDY_DEVICE        device index for SPDY_DEVICE_AUTO              SPDY_FUSED = 0 | 1   initial spdy_plan_set_fused mode
  *   SPDY_WG_PER_CU     persistent workgroups per CU of the T30 kernels (default 1)
  *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1
  *   SPDY_T63_NOSPLIT   one workgroup per pair in small T63 direct launches instead of two (same bits)
- *   SPDY_T63_TRI=1     T63 direct batches as three field pairs per workgroup (csrc/spdy_t63_tri.inc; same bits, slower: opt-in)
+ *   SPDY_T63_NODERIVE  T63 model-sized inverse batches run uvspec / grad as an operator kernel in front of the transform launch instead
+ *                      of evaluating them where the transform loads its operands (agree to rounding)
  *   SPDY_T63_NOSTAGE   small T63 direct batches run fused (row FFTs inside the contraction launch) instead of staged (same bits)
  *   SPDY_T63_NP2_FROM  pairs from which the staged contraction takes two pairs per workgroup (default 40; same bits)
  *   SPDY_T30_NOSPLIT   small T30 direct batches as whole tiles instead of three workgroups per tile (same bits)
  *   SPDY_WT_MIN_MB     output size (MB, default 6) from which a model-sized launch writes its output through the L2s instead of
  *                      leaving it dirty for the end-of-kernel release (0 = never; same bits either way)
- *   SPDY_COMM_TIMEOUT_S  seconds (> 0, read once; default 120) an in-process collective waits for its missing ranks before it breaks the group
+ *   SPDY_COMM_TIMEOUT_S  seconds (> 0; default 120; read when a group is created) an in-process collective waits for its missing ranks before it breaks the group
  *   SPDY_T30_NOPART    small T30 inverse launches walk whole tiles instead of (tile, third of the latitudes) items (same bits)
  *   SPDY_COMM_DRY=1    RCCL communicators created under it skip their collectives (timing a sharded step without its
  *                      exchanges; results are then wrong)
@@ -123,6 +126,13 @@ int spdy_plan_set_profiling(spdy_plan *plan, int on);
  * non-temporal loads/stores (the data passes through the caches once); smaller ones leave it cached for their
  * consumer.                                                                                        */
 int spdy_plan_set_fused(spdy_plan *plan, int mode);
+/* Launch-policy switches of one plan (measurement and test aids; same results, see the environment list above -- the
+ * environment gives a plan its initial values when it is created and is not read again).  name / value:
+ *   "t30_part", "t30_split", "t63_split", "t63_stage", "t63_derive"   0 = the form named by $SPDY_T30_NOPART, $SPDY_T30_NOSPLIT,
+ *                       $SPDY_T63_NOSPLIT, $SPDY_T63_NOSTAGE, $SPDY_T63_NODERIVE; 1 = the default form
+ *   "t63_np2_from" >= 1, "wt_min_mb" >= 0                              as $SPDY_T63_NP2_FROM, $SPDY_WT_MIN_MB
+ * Not while a graph capture is open (SPDY_ERR_STATE); captured graphs keep the forms they were captured with.       */
+int spdy_plan_set_option(spdy_plan *plan, const char *name, int value);
 int spdy_plan_get_profile(spdy_plan *plan, double *ms, int *launches);
 /* Diagnostic: where the dispatcher places the eight waves of a workgroup shaped like the fused T63 kernels' (512 threads,
  * their LDS footprint, one workgroup per CU).  simd_of_wave[0..7] = SIMD of waves 0..7 of workgroup 0; violations = how many of

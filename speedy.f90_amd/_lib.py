@@ -26,6 +26,7 @@ SIGNATURES = {
     "spdy_wave_placement": [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "spdy_plan_set_profiling": [c_void_p, c_int],
     "spdy_plan_set_fused": [c_void_p, c_int],
+    "spdy_plan_set_option": [c_void_p, c_char_p, c_int],
     "spdy_plan_get_profile": [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int)],
     "spdy_get_table": [c_void_p, c_char_p, c_void_p, c_int],
     "spdy_spec_to_grid": [c_void_p, c_void_p, c_int, c_void_p],

@@ -121,7 +121,7 @@ void build_packed_tables(const HostTables &t, int ks_inv, int js_dir, std::vecto
 // one double2 per lane and latitude chunk; 4x4x4 block = zonal wavenumber 4q+blk, A row = lane&3, k = lane>>4.
 //   direct : A[i = n row][k = lat]  = P(m,n,lat)*wt(lat),  .x/.y = the chunk's two k-steps of 4 latitudes
 //   inverse: A[i = lat][k = n]      = P(m,n,lat),          .x/.y = the chunk's two groups of 4 latitudes
-void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector<double> &inv, std::vector<double> &tri)
+void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector<double> &inv)
 {
     using namespace spdy::t63;
     const int mx = t.mx, nx = t.nx;
@@ -151,13 +151,6 @@ void build_t63_images(const HostTables &t, std::vector<double> &dir, std::vector
                                 }
                     }
         }
-    // the direct image by sub-chunk (one k-step of 4 latitudes: sub-chunk 2 c + h = chunk c, k-step h), two slots per double2
-    tri.assign((size_t)NLW * TSC * TS2 * 64 * 2, 0.0);
-    for (int w = 0; w < NLW; ++w)
-        for (int s = 0; s < nslots(true, w); ++s)
-            for (int sc = 0; sc < TSC; ++sc)
-                for (int lane = 0; lane < 64; ++lane)
-                    tri[((size_t)tri_frag(w, sc, s >> 1) * 64 + lane) * 2 + (s & 1)] = dir[((size_t)afrag(w, s, sc >> 1) * 64 + lane) * 2 + (sc & 1)];
 }
 
 int upload_all(spdy_plan *p)
@@ -232,12 +225,12 @@ int upload_all(spdy_plan *p)
                 }
         UP(is2g3, img_s2g3);
     }
-    d.img_g2s63 = d.img_s2g63 = d.img_g2s63t = nullptr;
+    d.img_g2s63 = d.img_s2g63 = nullptr;
     d.rows_ws = nullptr; d.rows_ws_fields = 0;
     if (t.trunc == 63) {
-        std::vector<double> i63d, i63i, i63t;
-        build_t63_images(t, i63d, i63i, i63t);
-        UP(i63d, img_g2s63); UP(i63i, img_s2g63); UP(i63t, img_g2s63t);
+        std::vector<double> i63d, i63i;
+        build_t63_images(t, i63d, i63i);
+        UP(i63d, img_g2s63); UP(i63i, img_s2g63);
         // row workspace of the staged small-batch direct transform (spdy_fused_t63.inc): a model step's direct batch is up to
         // three segments of at most max_batch fields, and the form only runs below one pair per two CUs -- model-shaped plans
         // get room for all of it (98 KB per field), throughput-sized plans for the 256 fields such a launch can have
@@ -377,14 +370,20 @@ int ensure_staging(spdy_plan *p, size_t elems)
                 if (ok) p->hstage[i] = static_cast<double *>(ptr);
             }
             if (ok) ok = hipHostMalloc(&ptr, sizeof(int) * (size_t)p->max_batch, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-            if (ok) { p->h_kcos = static_cast<int *>(ptr); p->hstage_elems = want; }
-            if (ok && hipHostMalloc(&ptr, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-                p->h_stamp = static_cast<unsigned *>(ptr);
-                *p->h_stamp = 0;
-            }
-            else {
+            if (ok) {
+                p->h_kcos = static_cast<int *>(ptr);
+                p->hstage_elems = want;
+                // the completion stamp is optional: without it sync() ends host-staged calls in hipStreamSynchronize
+                if (hipHostMalloc(&ptr, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+                    p->h_stamp = static_cast<unsigned *>(ptr);
+                    *p->h_stamp = 0;
+                } else
+                    (void)hipGetLastError();
+            } else {
+                // the route stays off as a whole: no buffers, no size, no kcos twin
                 (void)hipGetLastError();
                 for (int i = 0; i < 4; ++i) { if (p->hstage[i]) (void)hipHostFree(p->hstage[i]); p->hstage[i] = nullptr; }
+                p->hstage_elems = 0;
             }
         }
     }
@@ -440,12 +439,21 @@ int sync(spdy_plan *p)
     if (spin && p->h_stamp && !p->pending.empty()) {
         const unsigned seq = ++p->stamp_seq;
         hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, p->stream, p->h_stamp, seq);
-        if (hipGetLastError() == hipSuccess) {
+        if (hipPeekAtLastError() == hipSuccess) {          // (peek: an earlier sticky error stays for hipStreamSynchronize below to report)
+            // A bounded spin: a host-staged call's kernels take 10-60 us, so the stamp is normally there within a few hundred
+            // microseconds; past 2 ms the thread stops burning its core (hosts with several ranks or OpenMP threads per core)
+            // and sleeps in the runtime, which also reports an asynchronous kernel fault at once instead of after a timeout.
             const auto t0 = std::chrono::steady_clock::now();
             unsigned spins = 0;
             while (__atomic_load_n(p->h_stamp, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
-                if ((++spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;   // fall back to the runtime
+#elif defined(__aarch64__)
+                asm volatile("yield" ::: "memory");
+#else
+                asm volatile("" ::: "memory");
+#endif
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;   // fall back to the runtime
             }
             if (__atomic_load_n(p->h_stamp, __ATOMIC_ACQUIRE) == seq) {
                 for (const auto &c : p->pending) std::memcpy(c.dst, c.src, c.bytes);
@@ -601,6 +609,15 @@ int spdy_plan_create(int trunc, int ix, int iy, int kx, int max_batch, int devic
                 p->num_cu = prop.multiProcessorCount;
             if (const char *env = getenv("SPDY_FUSED")) p->fused_mode = atoi(env);
             if (const char *env = getenv("SPDY_WG_PER_CU")) p->wg_per_cu = atoi(env) >= 1 ? atoi(env) : 1;
+            // launch-policy switches: the environment is read HERE, once per plan; afterwards spdy_plan_set_option
+            spdy::LaunchOpts &lo = p->dev.lo;
+            lo.t30_nopart = getenv("SPDY_T30_NOPART") != nullptr;
+            lo.t30_nosplit = getenv("SPDY_T30_NOSPLIT") != nullptr;
+            lo.t63_nosplit = getenv("SPDY_T63_NOSPLIT") != nullptr;
+            lo.t63_nostage = getenv("SPDY_T63_NOSTAGE") != nullptr;
+            if (const char *env = getenv("SPDY_T63_NP2_FROM")) lo.t63_np2_from = atoi(env);
+            if (const char *env = getenv("SPDY_WT_MIN_MB")) lo.wt_min_mb = atoi(env) > 0 ? atoi(env) : 0;
+            p->t63_derive = getenv("SPDY_T63_NODERIVE") == nullptr;
         }
         if (!rc) rc = upload_all(p);
         if (rc) {
@@ -729,6 +746,24 @@ int spdy_plan_set_fused(spdy_plan *p, int mode)
         RC(ensure_four(p));
     }
     p->fused_mode = mode;
+    return SPDY_OK;
+}
+
+int spdy_plan_set_option(spdy_plan *p, const char *name, int value)
+{
+    NEED_PLAN(p);
+    if (!name) return fail(SPDY_ERR_ARG, "null option name");
+    if (p->capturing) return fail(SPDY_ERR_STATE, "launch options cannot change while a graph capture is open");
+    spdy::LaunchOpts &lo = p->dev.lo;
+    const std::string n(name);
+    if (n == "t30_part") lo.t30_nopart = !value;
+    else if (n == "t30_split") lo.t30_nosplit = !value;
+    else if (n == "t63_split") lo.t63_nosplit = !value;
+    else if (n == "t63_stage") lo.t63_nostage = !value;
+    else if (n == "t63_derive") p->t63_derive = value != 0;
+    else if (n == "t63_np2_from") { if (value < 1) return fail(SPDY_ERR_ARG, "t63_np2_from must be >= 1"); lo.t63_np2_from = value; }
+    else if (n == "wt_min_mb") { if (value < 0) return fail(SPDY_ERR_ARG, "wt_min_mb must be >= 0"); lo.wt_min_mb = value; }
+    else return fail(SPDY_ERR_ARG, "unknown launch option '%s'", name);
     return SPDY_OK;
 }
 
@@ -974,6 +1009,29 @@ int spdy_uvspec_dev(spdy_plan *p, int nb, const double *vor, const double *dv, d
     KERNEL(spdy::launch_uvspec(p->dev, nb, vor, dv, u, v, p->stream));
     return SPDY_OK;
 }
+/* T63, row f1: uvspec / grad evaluated where the fused inverse kernel loads its operands (csrc/spdy_fused_t63.inc,
+ * t63_inv_load_b_op) -- segments U, V of (vor, div) and d/dlambda, d/dmu of psi.  Model-sized launches only; larger ones keep
+ * the operator kernel in front (it runs at 4-6 TB/s there and the transform launch is not latency-bound).  $SPDY_T63_NODERIVE /
+ * spdy_plan_set_option("t63_derive", 0): always the operator kernel (A/B runs, the determinism test).                        */
+static int append_uv_segs(spdy::T63Batch &b, int k, int npairs, const double *vor, const double *dv, double *ug, double *vg, int kcos)
+{
+    b.seg[k++] = spdy::T63Seg{vor, ug, dv, nullptr, npairs, kcos, 0, spdy::T63_OP_U};
+    b.seg[k++] = spdy::T63Seg{dv, vg, vor, nullptr, npairs, kcos, 0, spdy::T63_OP_V};
+    return k;
+}
+static int append_grad_segs(spdy::T63Batch &b, int k, int ngrad, const double *psi, double *gx, double *gy, int kcos)
+{
+    b.seg[k++] = spdy::T63Seg{psi, gx, psi, nullptr, ngrad, kcos, 0, spdy::T63_OP_GX};
+    b.seg[k++] = spdy::T63Seg{psi, gy, psi, nullptr, ngrad, kcos, 0, spdy::T63_OP_GY};
+    return k;
+}
+static bool derive63(const spdy_plan *p, int op_fields_each, int nsets, int plain_fields_pairs)
+{
+    // op_fields_each fields in each of nsets derived segments (pairs are formed inside a segment)
+    const int op_pairs = nsets * ((op_fields_each + 1) / 2);
+    return p->t63_derive && spdy::s2g_t63_derives(p->num_cu, op_pairs + plain_fields_pairs, op_pairs);
+}
+
 /* uvspec / grad followed by the two inverse transforms their callers always do, in one pass where the fused
  * kernels exist; otherwise the operator kernel into plan-owned temporaries and two ordinary transforms.      */
 static int derived_to_grid(spdy_plan *p, int nb, int mode, const double *in0, const double *in1, double *g0, double *g1, int kcos)
@@ -986,6 +1044,11 @@ static int derived_to_grid(spdy_plan *p, int nb, int mode, const double *in0, co
         return timed(p, SPDY_K_S2G_FUSED, [&] {
             return spdy::launch_s2g_fused(p->dev, nb, in0, nullptr, kcos, g0, p->num_cu * p->wg_per_cu, p->stream, mode, in1, g1);
         });
+    if (use_fused63_composite(p) && derive63(p, nb, 2, 0)) {   // T63, model-sized: the operator rides in the transform launch
+        spdy::T63Batch b{};
+        b.nseg = mode == 1 ? append_uv_segs(b, 0, nb, in0, in1, g0, g1, kcos) : append_grad_segs(b, 0, nb, in0, g0, g1, kcos);
+        return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
+    }
     RC(ensure_four(p));
     if (mode == 1) KERNEL(spdy::launch_uvspec(p->dev, nb, in0, in1, p->tmp_c, p->tmp_d, p->stream));
     else {
@@ -1082,13 +1145,16 @@ int spdy_inverse_batch_dev(spdy_plan *p, int npairs, const double *vor, const do
                                           nplain, spec, d_kcos, kcos_all, grid);
         });
     if (npairs > 0 && nplain > 0 && use_fused63_composite(p)) {
-        // T63: uvspec, then the U, V and plain spectra as three segments of ONE fused launch
-        RC(ensure_four(p));
-        KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
+        // T63: U, V and the plain spectra as three segments of ONE fused launch; uvspec on load (model sizes) or as a kernel in front
         spdy::T63Batch b{};
         b.nseg = 3;
-        b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
-        b.seg[1] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        if (derive63(p, npairs, 2, (nplain + 1) / 2)) append_uv_segs(b, 0, npairs, vor, dv, ug, vg, kcos_pairs);
+        else {
+            RC(ensure_four(p));
+            KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
+            b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+            b.seg[1] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        }
         b.seg[2] = spdy::T63Seg{spec, grid, nullptr, d_kcos, nplain, kcos_all, 0, 0};
         return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
     }
@@ -1115,18 +1181,24 @@ int spdy_inverse_batch_grad_dev(spdy_plan *p, int npairs, const double *vor, con
                                           nplain, spec, d_kcos, kcos_all, grid, ngrad, psi, gx, gy, kcos_grad, p->d_zero_spec);
         });
     if (use_fused63_composite(p) && npairs > 0 && nplain > 0 && ngrad > 0 && npairs + ngrad <= p->max_batch) {
-        // T63: ONE operator launch (uvspec | grad) writes into the plan's temporaries, then U, V, d/dlambda, d/dmu and the plain spectra
-        // are five segments of ONE fused launch (the gradient alone would be a one-workgroup launch of a full pipeline latency)
-        RC(ensure_four(p));
-        const size_t off = (size_t)npairs * spec_elems(p);
-        KERNEL(spdy::launch_uvspec_grad(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
+        // T63: U, V, d/dlambda, d/dmu and the plain spectra are five segments of ONE fused launch (the gradient alone would be a
+        // one-workgroup launch of a full pipeline latency).  Model sizes: uvspec and grad are evaluated on load (row f1, round 6 --
+        // no operator launch); larger batches: ONE operator launch (uvspec | grad) into the plan's temporaries in front.
         spdy::T63Batch b{};
         b.nseg = 5;
-        b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
-        b.seg[1] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        if (derive63(p, npairs, 2, (nplain + 1) / 2 + 2 * ((ngrad + 1) / 2))) {
+            append_uv_segs(b, 0, npairs, vor, dv, ug, vg, kcos_pairs);
+            append_grad_segs(b, 3, ngrad, psi, gx, gy, kcos_grad);
+        } else {
+            RC(ensure_four(p));
+            const size_t off = (size_t)npairs * spec_elems(p);
+            KERNEL(spdy::launch_uvspec_grad(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
+            b.seg[0] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+            b.seg[1] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+            b.seg[3] = spdy::T63Seg{p->tmp_c + off, gx, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
+            b.seg[4] = spdy::T63Seg{p->tmp_d + off, gy, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
+        }
         b.seg[2] = spdy::T63Seg{spec, grid, nullptr, d_kcos, nplain, kcos_all, 0, 0};
-        b.seg[3] = spdy::T63Seg{p->tmp_c + off, gx, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
-        b.seg[4] = spdy::T63Seg{p->tmp_d + off, gy, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
         return timed(p, SPDY_K_S2G_FUSED, [&] { return spdy::launch_s2g_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
     }
     RC(spdy_inverse_batch_dev(p, npairs, vor, dv, ug, vg, kcos_pairs, nplain, spec, d_kcos, kcos_all, grid));
@@ -1168,21 +1240,29 @@ int spdy_inverse_batch_segs_dev(spdy_plan *p, int npairs, const double *vor, con
         });
     }
     if (use_fused63_composite(p) && npairs > 0 && npairs + ngrad <= p->max_batch) {
-        // T63: one operator launch (uvspec | grad), then U, V, the gradient pair and every source array are segments of ONE fused launch
-        RC(ensure_four(p));
+        // T63: U, V, the gradient pair and every source array are segments of ONE fused launch; uvspec | grad on load at model sizes
+        // (row f1, round 6), otherwise as one operator launch in front
+        int plain_pairs = 0;
+        for (int i = 0; i < ns; ++i) plain_pairs += (sg[i].nb + 1) / 2;
+        const bool derive = derive63(p, npairs, 2, plain_pairs + 2 * ((ngrad + 1) / 2));
         const size_t off = (size_t)npairs * spec_elems(p);
-        if (ngrad) KERNEL(spdy::launch_uvspec_grad(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
-        else KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
         spdy::T63Batch b{};
         int k = 0;
-        b.seg[k++] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
-        b.seg[k++] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        if (derive) k = append_uv_segs(b, k, npairs, vor, dv, ug, vg, kcos_pairs);
+        else {
+            RC(ensure_four(p));
+            if (ngrad) KERNEL(spdy::launch_uvspec_grad(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, ngrad, psi, p->tmp_c + off, p->tmp_d + off, p->stream));
+            else KERNEL(spdy::launch_uvspec(p->dev, npairs, vor, dv, p->tmp_c, p->tmp_d, p->stream));
+            b.seg[k++] = spdy::T63Seg{p->tmp_c, ug, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+            b.seg[k++] = spdy::T63Seg{p->tmp_d, vg, nullptr, nullptr, npairs, kcos_pairs, 0, 0};
+        }
         size_t first = 0;
         for (int i = 0; i < ns; ++i) {
             b.seg[k++] = spdy::T63Seg{sg[i].d_spec, grid + first * grid_elems(p), nullptr, d_kcos ? d_kcos + first : nullptr, sg[i].nb, kcos_all, 0, 0};
             first += sg[i].nb;
         }
-        if (ngrad) {
+        if (ngrad && derive) k = append_grad_segs(b, k, ngrad, psi, gx, gy, kcos_grad);
+        else if (ngrad) {
             b.seg[k++] = spdy::T63Seg{p->tmp_c + off, gx, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
             b.seg[k++] = spdy::T63Seg{p->tmp_d + off, gy, nullptr, nullptr, ngrad, kcos_grad, 0, 0};
         }

@@ -67,6 +67,7 @@ struct spdy_comm_group {
     unsigned long generation = 0;
     bool broken = false;
     int attached = 0;
+    double timeout_s = 120.0;         // $SPDY_COMM_TIMEOUT_S at spdy_comm_group_create (a value that is not a positive number keeps the default)
     std::vector<spdy_comm *> member;
     std::vector<hipEvent_t> ready, done;
     std::vector<int> device;
@@ -147,17 +148,14 @@ int group_barrier(spdy_comm_group *g)
         g->cv.notify_all();
         return SPDY_OK;
     }
-    static const double limit = [] {                         // parsed once; a value that is not a positive number keeps the default
-        const char *env = getenv("SPDY_COMM_TIMEOUT_S");
-        const double v = env ? atof(env) : 0.0;
-        return v > 0.0 ? v : 120.0;
-    }();
+    const double limit = g->timeout_s;
     if (!g->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return g->generation != gen || g->broken; })) {
+        const int arrived = g->arrived;
         g->broken = true;
         g->arrived = 0;
         g->cv.notify_all();
         return fail(SPDY_ERR_COMM, "in-process collective: %d of %d ranks arrived within %.0f s (each rank must call from its own thread)",
-                    g->arrived, g->nranks, limit);
+                    arrived, g->nranks, limit);
     }
     if (g->broken) return fail(SPDY_ERR_COMM, "in-process communicator group is broken");
     return SPDY_OK;
@@ -273,6 +271,7 @@ int spdy_comm_group_create(int nranks, spdy_comm_group **grp)
     if (nranks < 1 || nranks > 64) return fail(SPDY_ERR_ARG, "1..64 ranks per in-process group, not %d", nranks);
     spdy_comm_group *g = new spdy_comm_group;
     g->nranks = nranks;
+    if (const char *env = getenv("SPDY_COMM_TIMEOUT_S")) { const double v = atof(env); if (v > 0.0) g->timeout_s = v; }   // once per group
     g->member.assign(nranks, nullptr);
     g->ready.assign(nranks, nullptr);
     g->done.assign(nranks, nullptr);
@@ -289,11 +288,15 @@ int spdy_comm_group_destroy(spdy_comm_group *g)
         std::lock_guard<std::mutex> lk(g->mu);
         if (g->attached) return fail(SPDY_ERR_STATE, "%d communicators of the group are still alive", g->attached);
     }
+    int caller_device = -1;
+    const bool have_device = hipGetDevice(&caller_device) == hipSuccess;
     for (int q = 0; q < g->nranks; ++q) {                    // the ranks' events: created on first attach, owned by the group
         if (g->device[q] >= 0) (void)hipSetDevice(g->device[q]);
         if (g->ready[q]) (void)hipEventDestroy(g->ready[q]);
         if (g->done[q]) (void)hipEventDestroy(g->done[q]);
     }
+    if (have_device) (void)hipSetDevice(caller_device);      // the calling thread keeps its device
+    else (void)hipGetLastError();
     delete g;
     return SPDY_OK;
 }

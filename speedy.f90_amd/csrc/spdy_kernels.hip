@@ -863,7 +863,6 @@ __global__ void hdiff_kernel(int sz, long total, const double *__restrict__ fiel
 
 #include "spdy_fused_t30.inc"
 #include "spdy_fused_t63.inc"
-#include "spdy_t63_tri.inc"
 
 // ------------------------------------------------------------------------------------------
 // Launchers
@@ -880,7 +879,6 @@ __global__ void wave_placement_kernel(int *out);
 hipError_t prepare_device_kernels()
 {
     struct { const void *fn; int bytes; } big[] = {
-#define SPDY_K3(k_, m_) {reinterpret_cast<const void *>(k_<m_, false, t63::TNP>), t63::tri_lds_bytes(t63::TNP)}, {reinterpret_cast<const void *>(k_<m_, true, t63::TNP>), t63::tri_lds_bytes(t63::TNP)}
 #define SPDY_K2(k_, m_, b_) {reinterpret_cast<const void *>(k_<m_, false>), b_}, {reinterpret_cast<const void *>(k_<m_, true>), b_}
         SPDY_K2(s2g_fused_t30_kernel, 0, t30::S2G_LDS), SPDY_K2(s2g_fused_t30_kernel, 1, t30::S2G_LDS),
         SPDY_K2(s2g_fused_t30_kernel, 2, t30::S2G_LDS), SPDY_K2(s2g_fused_t30_kernel, 3, t30::S2G_LDS),
@@ -895,10 +893,10 @@ hipError_t prepare_device_kernels()
 #undef SPDY_K2
         {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, false>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(s2g_fused_t63_kernel<true, false>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, true>), t63::LDS_BYTES},
+        {reinterpret_cast<const void *>(s2g_fused_t63_kernel<false, true, true>), t63::LDS_BYTES},
         // the two-workgroups-per-pair form of small direct batches (every model-sized T63 batch, the captured step)
         {reinterpret_cast<const void *>(g2s_fused_t63_kernel<0, false, true>), t63::LDS_BYTES}, {reinterpret_cast<const void *>(g2s_fused_t63_kernel<1, false, true>), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(g2s_rows_t63_kernel<0>), (4 * 16 * t63::RS + t63::TW) * 8 + 4 * 68}, {reinterpret_cast<const void *>(g2s_rows_t63_kernel<1>), (4 * 16 * t63::RS + t63::TW) * 8 + 4 * 68},
-        SPDY_K3(g2s_tri_t63_kernel, 0), SPDY_K3(g2s_tri_t63_kernel, 1),
         {reinterpret_cast<const void *>(wave_placement_kernel), t63::LDS_BYTES},
         {reinterpret_cast<const void *>(legendre_inv_kernel<3>), 104 * 1024}, {reinterpret_cast<const void *>(legendre_dir_kernel<3>), 104 * 1024}};   // T63: 73,856 / 98,432 B
     for (auto &b : big) {

@@ -4,6 +4,18 @@
 
 namespace spdy {
 
+// Launch-policy switches of a plan (host-side use: which kernel form a launcher picks; none changes results beyond the
+// rounding-level path choices documented in include/spdy.h).  Read from the environment ONCE, at plan creation
+// (spdy_plan_create), and changed per plan with spdy_plan_set_option -- no launcher calls getenv.
+struct LaunchOpts {
+    int t30_nopart = 0;     // small T30 inverse launches walk whole tiles              ($SPDY_T30_NOPART,  "t30_part" = 0)
+    int t30_nosplit = 0;    // small T30 direct launches as whole tiles                 ($SPDY_T30_NOSPLIT, "t30_split" = 0)
+    int t63_nosplit = 0;    // one workgroup per pair in small fused T63 direct launches ($SPDY_T63_NOSPLIT, "t63_split" = 0)
+    int t63_nostage = 0;    // small T63 direct batches fused instead of staged         ($SPDY_T63_NOSTAGE, "t63_stage" = 0)
+    int t63_np2_from = 40;  // pairs from which the staged contraction takes two pairs per workgroup ($SPDY_T63_NP2_FROM)
+    int wt_min_mb = 6;      // output MB from which a model-sized launch writes through ($SPDY_WT_MIN_MB; 0 = never)
+};
+
 // Device-side view of a plan: dimensions + table pointers (all device memory).
 struct DevPlan {
     int trunc, ix, iy, il, kx, nx, mx;
@@ -26,9 +38,6 @@ struct DevPlan {
     const double *img_s2g3; // [3 parts][4 Legendre waves][10][64 lanes][2]
     // A-operand images of the fused T63 kernels: [4 Legendre waves][38 slots][6 chunks][64 lanes][2] (spdy_t63_sched.hpp)
     const double *img_g2s63, *img_s2g63;
-    // the direct image regrouped for the three-pairs-per-workgroup kernel (spdy_t63_tri.inc):
-    // [4 waves][12 sub-chunks of 4 latitudes][19 fragment pairs][64 lanes][2] = (slot 2 s2, slot 2 s2 + 1) of one k-step
-    const double *img_g2s63t;
     // row workspace of the staged form of small T63 direct batches: [pair][chunk][field][16 rows][128] Fourier rows
     double *rows_ws;
     int rows_ws_fields;     // capacity in fields (0: none -- the fused split form runs instead)
@@ -50,6 +59,7 @@ struct DevPlan {
     const double *dmp_t[6]; // dmp, dmpd, dmps, dmp1, dmp1d, dmp1s [nx][mx] (dmp1* valid after spdy_implicit_init)
     const double *coriol;   // [il] 2*omega*sin(lat) (geometry.f90:89), southernmost row first
     double rgas, akap;      // physical_constants.f90:22-24 (float32 literals widened)
+    LaunchOpts lo;          // (host-side use, like num_cu)
 };
 constexpr int LEVTAB_COUNT = 12;   // number of per-level tables above (one device allocation of LEVTAB_COUNT*kx doubles)
 
@@ -118,9 +128,13 @@ struct T63Batch {
     int nseg, npairs;
     int by_chunk, wt;      // inverse, small batches: work items are (pair, chunk) instead of whole pairs; model-sized launches with
                            // several MB of output: stores written through (both set by the launcher)
+    int nop_items, ipw;    // by-chunk walk (set by the launcher): items of the derived segments (one per workgroup), items per
+                           // workgroup behind them
     T63Seg seg[T63_MAX_SEG];
 };
 hipError_t launch_s2g_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
+// whether an inverse launch of `pairs` field pairs may carry `op_pairs` derived ones (model-sized launches: the by-chunk form)
+bool s2g_t63_derives(int max_wg, int pairs, int op_pairs);
 hipError_t launch_g2s_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
 hipError_t launch_g2s_fused_t63(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg, hipStream_t s);
 
@@ -182,9 +196,9 @@ struct GridTend {
     LevelShard sh;
 };
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
-// Write-through policy of a model-sized launch (the step's kernels): outputs of at least SPDY_WT_MIN_MB (default 6; env
-// override, 0 = never) leave the L2s as they are produced instead of waiting, dirty, for the end-of-kernel release.
-bool write_through_policy(long output_bytes);
+// Write-through policy of a model-sized launch (the step's kernels): outputs of at least p.lo.wt_min_mb MB (default 6; 0 = never)
+// leave the L2s as they are produced instead of waiting, dirty, for the end-of-kernel release.
+bool write_through_policy(const DevPlan &p, long output_bytes);
 hipError_t launch_tendency_combine(const DevPlan &p, double *pdiv, double *pspec, hipStream_t s);
 // the whole spectral-space tail of a step in one launch (kx <= 16)
 struct SpecStep {

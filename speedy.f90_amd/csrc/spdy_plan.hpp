@@ -52,6 +52,7 @@ struct spdy_plan {
     int num_cu = 256;
     int wg_per_cu = 1;                // fused kernels: one 448-thread wave-specialised workgroup per CU
     int fused_mode = -1;              // -1 auto, 0 four-kernel path, 1 fused kernels (T30 only)
+    bool t63_derive = true;           // T63 model-sized inverse batches evaluate uvspec / grad on load ($SPDY_T63_NODERIVE, spdy_plan_set_option)
     // optional per-kernel timing (HIP events on the launch stream)
     bool profiling = false;
     bool capturing = false;           // between spdy_graph_begin and spdy_graph_end

@@ -478,7 +478,7 @@ hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream
         constexpr int bx = GT_BX;
         const dim3 grd((gsz + bx - 1) / bx), blk(bx, p.kx);
         const size_t lds = grid_tendencies_lds(p.kx, bx);
-        const bool wt = write_through_policy((long)(9 * p.kx + 1) * gsz * 8);     // the launch's output: [3kx] + [3kx] + [3kx+1] grids
+        const bool wt = write_through_policy(p, (long)(9 * p.kx + 1) * gsz * 8);     // the launch's output: [3kx] + [3kx] + [3kx+1] grids
 #define GT_LAUNCH(KM_, FULL_)                                                                                     \
     do {                                                                                                          \
         if (wt) hipLaunchKernelGGL((grid_tendencies_kernel<KM_, FULL_, false, true>), grd, blk, lds, s, p, g);    \

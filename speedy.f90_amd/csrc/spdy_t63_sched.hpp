@@ -40,12 +40,6 @@ constexpr int nslots(bool dir, int w) { return slot_of(dir, w, 4, 0, 0); }
 #endif
 constexpr int afrag(int w, int s, int c) { return T63_ALAYOUT ? (w * NCH + c) * MAXS + s : (w * MAXS + s) * NCH + c; }
 constexpr int AFRAG_SLOT_STRIDE = T63_ALAYOUT ? 1 : NCH;    // fragments between consecutive slots of one (wave, chunk)
-// Three-pairs-per-workgroup direct kernel (spdy_t63_tri.inc): sub-chunks of ONE k-step (4 latitude pairs), operand fragments
-// of two slots per 16-byte load
-constexpr int TNP = 3;                                       // field pairs per tile
-constexpr int TSC = IY / 4;                                  // 12 sub-chunks
-constexpr int TS2 = (MAXS + 1) / 2;                          // 19 fragment pairs per (wave, sub-chunk)
-constexpr int tri_frag(int w, int sc, int s2) { return (w * TSC + sc) * TS2 + s2; }
 static_assert(nslots(true, 0) <= MAXS && nslots(true, 1) <= MAXS && nslots(true, 2) <= MAXS && nslots(true, 3) <= MAXS, "direct slots");
 static_assert(nslots(false, 0) <= MAXS && nslots(false, 1) <= MAXS && nslots(false, 2) <= MAXS && nslots(false, 3) <= MAXS, "inverse slots");
 }  // namespace t63

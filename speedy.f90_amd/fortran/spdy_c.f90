@@ -318,6 +318,13 @@ module spdy_c
             integer(c_int), value :: mode
             integer(c_int) :: rc
         end function
+        function spdy_plan_set_option(plan, name, value) bind(C, name="spdy_plan_set_option") result(rc)
+            import :: c_char, c_int, c_ptr
+            type(c_ptr), value :: plan
+            character(kind=c_char), intent(in) :: name(*)     ! NUL-terminated
+            integer(c_int), value :: value
+            integer(c_int) :: rc
+        end function
         function spdy_plan_get_profile(plan, ms, launches) bind(C, name="spdy_plan_get_profile") result(rc)
             import :: c_double, c_int, c_ptr
             type(c_ptr), value :: plan

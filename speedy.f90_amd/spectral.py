@@ -293,6 +293,11 @@ class Spectral:
         """1 / -1 (default) = fused single-pass kernels (T30, T63) at every batch size, 0 = four-kernel path."""
         check(self.lib.spdy_plan_set_fused(self.h, int(mode)))
 
+    def set_option(self, name, value):
+        """Launch-policy switch of this plan (spdy_plan_set_option): "t30_part", "t30_split", "t63_split", "t63_stage",
+        "t63_derive" (0 / 1), "t63_np2_from", "wt_min_mb"."""
+        check(self.lib.spdy_plan_set_option(self.h, name.encode(), int(value)))
+
     def wave_placement(self):
         """(SIMD of waves 0..7 of workgroup 0, number of workgroups that violate the round-robin placement the T63 kernels'
         role assignment relies on) -- spdy_wave_placement."""

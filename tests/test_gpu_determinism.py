@@ -97,9 +97,9 @@ def test_t30_small_batch_forms_agree(nb, monkeypatch):
         sp.synchronize()
         return out
     a = run()
-    monkeypatch.setenv("SPDY_T30_NOPART", "1")
+    sp.set_option("t30_part", 0)          # (= a plan created under SPDY_T30_NOPART: the environment is read once per plan)
     b = run()
-    monkeypatch.delenv("SPDY_T30_NOPART")
+    sp.set_option("t30_part", 1)
     c = run()
     for k in a:
         assert not torch.isnan(a[k]).any(), k
@@ -113,7 +113,7 @@ def test_t30_small_direct_forms_agree(nb, monkeypatch):
     """Small T30 direct launches (at most a sixth as many tiles as CUs: the T30 L8 step's launch, every one-field call) run
     with THREE workgroups per tile -- all three do the tile's row FFTs, each contracts and stores a third of the zonal
     wavenumbers (csrc/spdy_fused_t30.inc, NSPLIT).  Every coefficient is the same chain of matrix instructions either way: the
-    split form, the whole-tile form (SPDY_T30_NOSPLIT) and a large batch's persistent walk must agree BIT FOR BIT in every mode
+    split form, the whole-tile form (option t30_split = 0) and a large batch's persistent walk must agree BIT FOR BIT in every mode
     of the kernel: plain fields, fields with a latitude factor, the vdspec pairs, a model step's mixed direct batch."""
     import torch
     import speedy_f90_amd as s
@@ -132,9 +132,9 @@ def test_t30_small_direct_forms_agree(nb, monkeypatch):
         sp.synchronize()
         return out
     a = run()
-    monkeypatch.setenv("SPDY_T30_NOSPLIT", "1")
+    sp.set_option("t30_split", 0)
     b = run()
-    monkeypatch.delenv("SPDY_T30_NOSPLIT")
+    sp.set_option("t30_split", 1)
     for k in a:
         assert not torch.isnan(torch.view_as_real(a[k])).any(), k
         assert torch.equal(a[k], b[k]), (nb, k)
@@ -151,7 +151,7 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
     """Small T63 direct batches (at most half as many pairs as CUs) run STAGED -- the row FFTs as a launch of their own over
     (pair, chunk, field) items, then the fused kernel's Legendre waves fed by movers (csrc/spdy_fused_t63.inc) -- instead of one
     fused launch whose eight steps are each as long as one FFT wave's phase.  Same code for every row, same accumulation order:
-    the staged form, the fused split form (SPDY_T63_NOSTAGE) and a large batch's whole-pair walk must agree BIT FOR BIT, for plain
+    the staged form, the fused split form (option t63_stage = 0) and a large batch's whole-pair walk must agree BIT FOR BIT, for plain
     fields, for the scaled pairs of vdspec and for a model step's three-segment direct batch."""
     import torch
     import speedy_f90_amd as s
@@ -170,9 +170,9 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
         sp.synchronize()
         return out
     a = run()
-    monkeypatch.setenv("SPDY_T63_NOSTAGE", "1")
+    sp.set_option("t63_stage", 0)
     b = run()
-    monkeypatch.delenv("SPDY_T63_NOSTAGE")
+    sp.set_option("t63_stage", 1)
     for k in a:
         assert not torch.isnan(torch.view_as_real(a[k])).any(), k
         assert torch.equal(a[k], b[k]), (nb, k)
@@ -184,61 +184,10 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
     sp.close()
 
 
-@pytest.mark.parametrize("nb", [1, 2, 5, 6, 9, 96, 255])
-def test_t63_three_pair_direct_form_agrees(nb, monkeypatch):
-    """Throughput-sized T63 direct batches run THREE field pairs per workgroup, every Legendre operand fragment feeding three
-    matrix instructions (csrc/spdy_t63_tri.inc: one wave per SIMD, accumulators in AGPRs, rows landing by LDS-DMA).  Same row FFT
-    code, same chain of matrix instructions per coefficient: with the form forced on at every batch size (SPDY_T63_TRI=1) the
-    spectra must equal the pair-per-workgroup forms (SPDY_T63_TRI=0) BIT FOR BIT -- plain fields incl. ragged tiles (1, 2, 5
-    fields: duplicated pairs and an absent second field), the scaled pairs of vdspec and a three-segment direct batch."""
-    import torch
-    import speedy_f90_amd as s
-    sp = s.Spectral("t63", kx=8, max_batch=600, device=0)
-    dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(977)
-    G = torch.from_numpy(rng.uniform(-0.5, 0.5, (600, sp.il, sp.ix))).to(dev)
-    npair = max(1, min(nb // 3, 48))
-    c128 = lambda n: torch.full((n, sp.nx, sp.mx), float("nan"), dtype=torch.complex128, device=dev)
-
-    def run():
-        out = {"plain": c128(nb), "vor": c128(npair), "div": c128(npair), "mvor": c128(npair), "mdiv": c128(npair), "mpl": c128(nb)}
-        sp.grid_to_spec_dev(G[:nb], out["plain"])
-        sp.vdspec_dev(G[:npair], G[npair:2 * npair], out["vor"], out["div"], 2)
-        sp.direct_batch_dev(G[:npair], G[npair:2 * npair], out["mvor"], out["mdiv"], G[100:100 + nb], out["mpl"], kcos=2)
-        sp.synchronize()
-        return out
-    monkeypatch.setenv("SPDY_T63_TRI", "0")
-    a = run()
-    monkeypatch.setenv("SPDY_T63_TRI", "1")
-    b = run()
-    big = c128(600)
-    sp.grid_to_spec_dev(G, big)
-    sp.synchronize()
-    monkeypatch.delenv("SPDY_T63_TRI")
-    for k in a:
-        assert not torch.isnan(torch.view_as_real(b[k])).any(), k
-        assert torch.equal(a[k], b[k]), (nb, k, float((torch.view_as_real(a[k]) - torch.view_as_real(b[k])).abs().max()))
-    assert torch.equal(big[:nb], a["plain"])
-    if nb == 255:
-        # ... and the scaled rows (vdspec's cos-latitude factor) in the STREAMING instantiation: 2 x 150 fields = 44 MB of grids
-        def scaled():
-            v, d = c128(150), c128(150)
-            sp.vdspec_dev(G[:150], G[150:300], v, d, 2)
-            sp.synchronize()
-            return v, d
-        monkeypatch.setenv("SPDY_T63_TRI", "0")
-        v0, d0 = scaled()
-        monkeypatch.setenv("SPDY_T63_TRI", "1")
-        v1, d1 = scaled()
-        monkeypatch.delenv("SPDY_T63_TRI")
-        assert torch.equal(v0, v1) and torch.equal(d0, d1)
-    sp.close()
-
-
 @pytest.mark.parametrize("tag,kx", [("t63", 8), ("t30", 8)])
 def test_write_through_policy_same_bits(tag, kx, monkeypatch):
     """Model-sized launches with several MB of output store it write-through (sc0 sc1) instead of write-back (csrc: write_through_policy,
-    $SPDY_WT_MIN_MB): a cache policy, not arithmetic.  The by-chunk inverse launch, the grid tendencies and (T63) the staged direct
+    option wt_min_mb): a cache policy, not arithmetic.  The by-chunk inverse launch, the grid tendencies and (T63) the staged direct
     launch must give the same bits with the policy forced on for every launch (1 MB) and switched off (0)."""
     import torch
     import speedy_f90_amd as s
@@ -260,9 +209,9 @@ def test_write_through_policy_same_bits(tag, kx, monkeypatch):
         sp.grid_to_spec_dev(U, back)
         sp.synchronize()
         return G, U, V, PL, back
-    monkeypatch.setenv("SPDY_WT_MIN_MB", "1")
+    sp.set_option("wt_min_mb", 1)
     a = run()
-    monkeypatch.setenv("SPDY_WT_MIN_MB", "0")
+    sp.set_option("wt_min_mb", 0)
     b = run()
     for i, (x, y) in enumerate(zip(a, b)):
         assert not torch.isnan(x.real if x.is_complex() else x).any(), i

@@ -51,6 +51,56 @@ def test_uvspec_and_grad_to_grid(res, nb, kcos, oracle_factory):
     sp.close()
 
 
+@pytest.mark.parametrize("nb", [1, 2, 5, 16, 20])
+def test_t63_operators_derived_on_load(nb, oracle_factory):
+    """Row f1 at T63 (round 6): model-sized inverse launches evaluate uvspec / grad where the fused kernel loads its operands
+    (csrc/spdy_fused_t63.inc: t63_inv_load_b_op -- the n +- 1 neighbours by lane exchange inside the wave, halo groups at the
+    edge of a wave's slots) instead of running an operator kernel in front.  Checked (a) against the reference's own call
+    sequence (uvspec / grad, then spec_to_grid: spectral.f90:98-110, 124-144, 173-196) through the oracle, at 1e-12, with the
+    dead part of the rhomboid (l > trunc + 1) holding finite junk -- the reference's stencils read those entries at n + 1,
+    whatever they hold, and so must the fold; (b) against the operator-kernel route of the same library (option
+    t63_derive = 0) at 1e-13; (c) as segments of the five-segment launch of a model step next to plain segments."""
+    import torch
+    import speedy_f90_amd as s
+    o = oracle_factory("t63")
+    sp = s.Spectral("t63", kx=8, max_batch=max(3 * nb + 1, 8), device=0)
+    sp.use_torch_stream()
+    S = synth.spectra(5 * nb + 2, sp.trunc, first=8100, full_rows=True)
+    rng = np.random.default_rng(808 + nb)
+    l = np.arange(sp.mx)[None, :] + np.arange(sp.nx)[:, None]
+    junk = rng.uniform(-1, 1, S.shape) + 1j * rng.uniform(-1, 1, S.shape)
+    S = np.where(l[None] > sp.trunc + 1, junk, S)                         # the transforms ignore it; the operators' n + 1 reads do not
+    dS = torch.from_numpy(S).cuda()
+    vor, div, spl, psi = dS[:nb], dS[nb:2 * nb], dS[2 * nb:5 * nb + 1], dS[5 * nb + 1:]
+    gs = (sp.il, sp.ix)
+    f64 = lambda n: torch.full((n,) + gs, float("nan"), dtype=torch.float64, device="cuda")
+
+    def run():
+        out = dict(ug=f64(nb), vg=f64(nb), gx=f64(nb), gy=f64(nb), mug=f64(nb), mvg=f64(nb), mpl=f64(3 * nb + 1), mgx=f64(1), mgy=f64(1))
+        sp.uvspec_to_grid_dev(vor, div, out["ug"], out["vg"], 2)
+        sp.grad_to_grid_dev(vor, out["gx"], out["gy"], 1)
+        sp.inverse_batch_grad_dev(vor, div, out["mug"], out["mvg"], spl, out["mpl"], psi, out["mgx"], out["mgy"], kcos_pairs=2, kcos=1, kcos_grad=2)
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in out.items()}
+    a = run()
+    sp.set_option("t63_derive", 0)
+    b = run()
+    sp.set_option("t63_derive", 1)
+    for k in a:
+        assert not np.isnan(a[k]).any(), k
+        ok(a[k], b[k], 1e-13)
+    for i in sorted({0, nb // 2, nb - 1}):
+        ru, rv = o.uvspec(S[i], S[nb + i])
+        ok(a["ug"][i], o.spec_to_grid(ru, 2)); ok(a["vg"][i], o.spec_to_grid(rv, 2))
+        ok(a["mug"][i], o.spec_to_grid(ru, 2)); ok(a["mvg"][i], o.spec_to_grid(rv, 2))
+        rdx, rdy = o.grad(S[i])
+        ok(a["gx"][i], o.spec_to_grid(rdx, 1)); ok(a["gy"][i], o.spec_to_grid(rdy, 1))
+    rdx, rdy = o.grad(S[5 * nb + 1])
+    ok(a["mgx"][0], o.spec_to_grid(rdx, 2)); ok(a["mgy"][0], o.spec_to_grid(rdy, 2))
+    ok(a["mpl"][3 * nb], o.spec_to_grid(S[5 * nb], 1))
+    sp.close()
+
+
 @pytest.mark.parametrize("res,nb", [("t30", 1), ("t30", 3), ("t30", 48), ("t30", 300), ("t63", 1), ("t63", 7)])
 @pytest.mark.parametrize("kcos", [2, 1])
 def test_vdspec_one_pass(res, nb, kcos, oracle_factory):
