@@ -229,6 +229,7 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
                                           sdrag, 2, 2400.0, rob, wil, phi, kcos=2)
     with sp.graph_capture() as g:
         one_step()
+    launches = g.num_nodes()
     for _ in range(5):
         g.launch()
     sp.synchronize()
@@ -254,8 +255,20 @@ def dynamics_step_time(s, torch, synth, res, kx, dev, reps=50):
     g8.close(); sp.close()
     # timing of the captured step on synthetic state (nothing runs outside the graph between replays); parity of this exact
     # sequence, replayed twice, is tests/test_gpu_step.py::test_dynamical_core_step_graph
-    return {"us_per_step": us, "us_per_step_eight_per_graph": us8, "launches_in_graph": 4 if res == "t30" else 6,
-            "transforms": 6 * kx + 2 + 9 * kx + 1, "levels": kx, "state_finite_after_replays": finite}
+    # SURVEY.md s8(d)'s byte model of a step: every transform's algorithmic bytes; per level 7 diffusion calls of 3 spectral arrays;
+    # the implicit solve's (2 kx + 1) spectral arrays read and written.  The step does NOT run at this roofline and is not
+    # expected to: it is a chain of `launches` dependent launches of 5-19 us, each on 70-200 workgroups of a 256-CU chip
+    # (launch / latency bound) -- the fraction is reported so that nobody has to guess it.
+    gs, ss, ntr = ix * il * 8, mx * nx * 16, 6 * kx + 2 + 9 * kx + 1
+    b_tr, b_hd, b_im = ntr * (gs + ss), kx * 7 * 3 * ss, 2 * (2 * kx + 1) * ss
+    model_bytes = b_tr + b_hd + b_im
+    return {"us_per_step": us, "us_per_step_eight_per_graph": us8, "launches_in_graph": launches,
+            "transforms": ntr, "levels": kx, "state_finite_after_replays": finite,
+            "roofline_step": {"bound": "launch latency (dependent launches on under-filled CUs), not hbm", "model": "SURVEY.md s8(d)",
+                              "bytes_transforms": b_tr, "bytes_hdiff": b_hd, "bytes_implicit": b_im, "bytes": model_bytes,
+                              "achieved_GBs": model_bytes / (us * 1e-6) / 1e9, "frac_of_8TBs": model_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "frac_of_8TBs_eight_per_graph": model_bytes / (us8 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "frac_of_8TBs_transforms_only": b_tr / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
 
 
 def headline_grids(torch, synth, sp, nb, rank, dev):
@@ -513,6 +526,50 @@ def fortran_step_loop():
             except Exception as e:
                 res[tag]["with_host_physics_hook"] = {"error": repr(e)}
     return res
+
+
+def flatten_for_driver(res, this_res):
+    """The driver's record of this line keeps the top-level scalars and the SCALAR members of `roofline`, `cpu_baseline` and
+    `config` (BENCH_rNN.json `parsed`; everything nested deeper, and `extras` as a whole, survives only as text in `tail`).
+    So what the survey asks to be reported beside `value` -- the other resolution (config 4), the captured time step with its
+    byte model (config 5), the rate with nothing cache-resident -- is repeated here as flat `roofline.*` scalars."""
+    rf, ex = res.get("roofline"), res.get("extras")
+    if not isinstance(rf, dict):
+        return
+    rf["path_hbm_frac"] = res.get("path_hbm_frac")
+    if not isinstance(ex, dict):
+        return
+    get = lambda d, *ks: (get(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    rf["path_hbm_frac_beyond_llc"] = get(ex, "round_trip_b24576", "path_hbm_frac")
+    rf["value_beyond_llc_rt_per_s"] = get(ex, "round_trip_b24576", "round_trips_per_s")
+    other = "t63" if this_res == "t30" else "t30"
+    o = ex.get(other + "_round_trip")
+    if isinstance(o, dict):
+        nb2, bpf = o.get("fields"), (214016 if other == "t63" else 52736)
+        rf[other + "_value_rt_per_s"] = o.get("round_trips_per_s_replayed")
+        rf[other + "_path_hbm_frac"] = (o.get("round_trips_per_s_replayed") or 0) * 2 * bpf / (HBM_PEAK_GBS * 1e9) or None
+        for k, us in (o.get("kernel_us") or {}).items():
+            rf["%s_%s_us" % (other, k)] = us
+            rf["%s_%s_frac" % (other, k)] = nb2 * bpf / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else None
+        rf[other + "_cpu_core_rt_per_s"] = get(o, "cpu_baseline", "value")
+    for tag in ("dynamics_step_t30_l8", "dynamics_step_t63_l16"):
+        d = ex.get(tag)
+        if isinstance(d, dict) and "us_per_step" in d:
+            short = tag.replace("dynamics_", "")
+            rf[short + "_us"] = d["us_per_step"]
+            rf[short + "_us_eight_per_graph"] = d.get("us_per_step_eight_per_graph")
+            rf[short + "_launches"] = d.get("launches_in_graph")
+            rf[short + "_model_bytes"] = get(d, "roofline_step", "bytes")
+            rf[short + "_frac"] = get(d, "roofline_step", "frac_of_8TBs")
+            rf[short + "_frac_transforms_only"] = get(d, "roofline_step", "frac_of_8TBs_transforms_only")
+            rf[short + "_bound"] = get(d, "roofline_step", "bound")
+            rf[short + "_cpu_reference_ms"] = get(d, "cpu_reference_step", "ms_per_step")
+    for k in ("direct_batch_6144", "inverse_batch_6144", "vdspec_one_pass", "uvspec_to_grid"):
+        rf["opfused_%s_frac" % k] = get(ex, k, "frac_of_8TBs")
+    cb, sock = res.get("cpu_baseline"), res.get("cpu_baseline_socket")
+    if isinstance(cb, dict) and isinstance(sock, dict):
+        cb["socket_value"], cb["socket_cores"], cb["socket_cpu"] = sock.get("value"), sock.get("cores"), get(sock, "host", "model")
+        cb["gpu_over_socket"] = res.get("gpu_over_cpu_socket")
 
 
 def collect_errors(node, path=""):
@@ -873,6 +930,7 @@ def main():
                 res["cpu_baseline_fast_math"] = fast
             res["cpu_baseline_socket"] = cpu_baseline_socket(args.res, "fast" if fast else "")
             res["gpu_over_cpu_socket"] = value / res["cpu_baseline_socket"]["value"]
+        flatten_for_driver(res, args.res)
         res["errors"] = collect_errors(res)          # every side measurement that failed, by path: none is hidden in a nested string
         print(json.dumps(res))
     sp.close()

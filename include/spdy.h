@@ -423,6 +423,9 @@ int spdy_graph_begin(spdy_plan *plan);
 int spdy_graph_end(spdy_plan *plan, spdy_graph **graph);
 int spdy_graph_launch(spdy_graph *graph);
 int spdy_graph_destroy(spdy_graph *graph);
+/* Number of nodes of a captured graph (one per kernel launch / collective of the captured calls): what bench.py and the
+ * step tests report as "launches per step". */
+int spdy_graph_num_nodes(spdy_graph *graph, int *nodes);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ SIGNATURES = {
     "spdy_graph_end": [c_void_p, ctypes.POINTER(c_void_p)],
     "spdy_graph_launch": [c_void_p],
     "spdy_graph_destroy": [c_void_p],
+    "spdy_graph_num_nodes": [c_void_p, ctypes.POINTER(c_int)],
 }
 
 

@@ -1430,6 +1430,16 @@ int spdy_graph_launch(spdy_graph *g)
     return SPDY_OK;
 }
 
+int spdy_graph_num_nodes(spdy_graph *g, int *nodes)
+{
+    if (!g || !nodes) return fail(SPDY_ERR_ARG, "null graph / output");
+    if (!g->graph) return fail(SPDY_ERR_STATE, "the graph has been destroyed");
+    size_t n = 0;
+    HIP_TRY(hipGraphGetNodes(g->graph, nullptr, &n));
+    *nodes = (int)n;
+    return SPDY_OK;
+}
+
 int spdy_graph_destroy(spdy_graph *g)
 {
     if (!g) return SPDY_OK;

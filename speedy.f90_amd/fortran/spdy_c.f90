@@ -272,6 +272,12 @@ module spdy_c
             type(c_ptr), value :: graph
             integer(c_int) :: rc
         end function
+        function spdy_graph_num_nodes(graph, nodes) bind(C, name="spdy_graph_num_nodes") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: graph
+            integer(c_int), intent(out) :: nodes
+            integer(c_int) :: rc
+        end function
         function spdy_graph_destroy(graph) bind(C, name="spdy_graph_destroy") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: graph

@@ -38,6 +38,12 @@ class Graph:
             self.sp._sync_stream()
         check(self.lib.spdy_graph_launch(self.h))
 
+    def num_nodes(self):
+        """Nodes of the captured graph: one per kernel launch / collective (spdy_graph_num_nodes)."""
+        n = ctypes.c_int(0)
+        check(self.lib.spdy_graph_num_nodes(self.h, ctypes.byref(n)))
+        return n.value
+
     def close(self):
         if self.h:
             self.lib.spdy_graph_destroy(self.h)
