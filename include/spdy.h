@@ -73,6 +73,7 @@ enum {
  *   SPDY_DEVICE        device index for SPDY_DEVICE_AUTO              SPDY_FUSED = 0 | 1   initial spdy_plan_set_fused mode
  *   SPDY_WG_PER_CU     persistent workgroups per CU of the T30 kernels (default 1)
  *   SPDY_COMM_FORCE=1  issue the collectives even at world size 1
+ *   SPDY_SHARD_TRANSPOSE=1  communicators created under it run the level-sharded step in its transposed form (spdy_comm_set_option)
  *   SPDY_T63_NOSPLIT   one workgroup per pair in small T63 direct launches instead of two (same bits)
  *   SPDY_T63_NODERIVE  T63 model-sized inverse batches run uvspec / grad as an operator kernel in front of the transform launch instead
  *                      of evaluating them where the transform loads its operands (agree to rounding)
@@ -348,6 +349,33 @@ int spdy_sharded_step_spectral_dev(spdy_comm *comm, double *vor, double *div, do
                                    const double *d_tcorh, const double *d_qcorh, double sdrag, int j1, double dt, double eps, double wil,
                                    double *phi, double *tend_out);
 int spdy_sharded_step_stacks(spdy_comm *comm, double **grid_stack, size_t *grid_doubles, double **spec_stack, size_t *spec_doubles);
+/* The TRANSPOSED form of the same step (spdy_comm_set_option(comm, "transpose", 1), or $SPDY_SHARD_TRANSPOSE=1 when the
+ * communicator is created; the all-gather form above stays the default).  Instead of gathering whole stacks and running the
+ * two column kernels redundantly on every rank, the ranks TRANSPOSE: the grid-space column kernel is coupled in the vertical
+ * but independent in the horizontal (tendencies.f90:109-197), the spectral step independent per coefficient
+ * (tendencies.f90:242-293, implicit.f90:168-217) -- so rank r runs them for ALL levels of ITS share of the grid points /
+ * coefficients (contiguous ranges in units of 16):
+ *     inverse batch (own levels)  ->  exchange 1: levels -> point ranges (6 kx slabs)  ->  grid tendencies, all levels of the own
+ *     points  ->  exchange 2 back: every rank's direct-batch operands come home (9 nl + 1 grids)  ->  direct batch incl. vds (own
+ *     levels)  ->  exchange 3: levels -> coefficient ranges (9 kx + nranks slabs)  ->  spectral step, all levels of the own
+ *     coefficients  ->  exchange 4 back (time level j2 of the own levels; ps whole), issued at the START of the next grid half.
+ * Each exchange is one grouped ncclSend / ncclRecv per peer on the plan's stream (in-process groups: 2-D peer copies).  Per rank
+ * and step it receives (R - 1) / R of 6 nl + 9 nl + 1 grids and 9 nl + 1 + 4 nl + 1 spectra -- a third of the all-gather form's
+ * bytes at 8 ranks (spdy_comm_describe prints both) -- and does 1 / R of the column kernels' work.  Same kernels' expressions
+ * on the same values: bit-identical to the all-gather form and to the unsharded step (tests/test_gpu_sharded_step.py).
+ * STATE: nothing is replicated any more.  After a transposed step the caller's prognostic arrays are current on (all levels x
+ * own coefficients) only; the next spdy_sharded_step_grid_dev completes what it reads IN PLACE in the caller's arrays (which is
+ * why they are not really const there), and spdy_sharded_state_gather_dev makes them whole on every rank (output, restart,
+ * switching the form).  phi and tend_out are written on the own coefficients; spdy_sharded_gather_ranges_dev completes any
+ * such array (rows of mx nx complex values; <= 4 kx + 2 rows).  The physics hook (spdy_sharded_step_operands between the two
+ * halves) is unchanged.                                                                                                      */
+int spdy_comm_set_option(spdy_comm *comm, const char *name, int value);      /* "transpose" 0 | 1; "force", "dry" as $SPDY_COMM_FORCE / _DRY */
+int spdy_sharded_state_gather_dev(spdy_comm *comm, double *vor, double *div, double *t, double *tr, double *ps);
+int spdy_sharded_gather_ranges_dev(spdy_comm *comm, int narr, double *const *arrays, const int *nrows);
+/* One line of JSON about the communicator: route ("rccl" with the path of the librccl the symbols were bound from -- a host
+ * process that carries two RCCL builds is a known source of hangs -- or the in-process group), rank / ranks, form, this rank's
+ * levels / points / coefficients, bytes received per step in either form.                                                   */
+int spdy_comm_describe(spdy_comm *comm, char *buf, int len);
 
 /* ---- fused operator + transform sequences (device-resident; extensions of the reference interface) ------
  * The reference's callers always follow uvspec by two spec_to_grid(.,2) (tendencies.f90:98-100, physics.f90:96-98)

@@ -95,6 +95,10 @@ SIGNATURES = {
     "spdy_sharded_step_operands": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                    ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "spdy_sharded_step_spectral_dev": [c_void_p] * 9 + [c_double, c_int, c_double, c_double, c_double, c_void_p, c_void_p],
+    "spdy_comm_set_option": [c_void_p, c_char_p, c_int],
+    "spdy_sharded_state_gather_dev": [c_void_p] * 6,
+    "spdy_sharded_gather_ranges_dev": [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int)],
+    "spdy_comm_describe": [c_void_p, c_char_p, c_int],
     "spdy_sharded_step_stacks": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(c_void_p),
                                  ctypes.POINTER(ctypes.c_size_t)],
     "spdy_grid_tendencies_dev": [c_void_p] * 12,

@@ -6,8 +6,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -28,6 +30,9 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    std::string path;                 // the file the symbols were bound from (dladdr): two RCCL builds in one job is a known source of hangs
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -45,8 +50,10 @@ Rccl &rccl()
     if (!(r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name)))) { r.error = std::string("librccl lacks ") + name; r.handle = nullptr; return r; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(GroupStart, "ncclGroupStart")
-    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
 #undef SYM
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(r.AllGather), &info) && info.dli_fname) r.path = info.dli_fname;
     return r;
 }
 }  // namespace
@@ -89,6 +96,15 @@ struct spdy_comm {
     double *U = nullptr, *V = nullptr, *PL = nullptr;   // this rank's direct-batch operands: 3 nl, 3 nl, 3 nl + 1 grids
     double *T = nullptr;              // level-block stack of the direct batches' outputs: 9 kx + nranks spectra
     double *tend = nullptr;           // final tendencies when the caller passes no array: 4 kx + 1 spectra
+    // the TRANSPOSED form of the step (spdy_comm_set_option "transpose"): levels <-> point ranges on the grid side, levels <->
+    // coefficient ranges on the spectral side (see transpose_blocks)
+    int transpose = 0;
+    bool ranges_valid = false;        // the caller's prognostics are current only on (all levels x own coefficients): the next grid
+                                      // half, or spdy_sharded_state_gather_dev, brings in what it reads
+    double *Gb = nullptr;             // gridded prognostics, all levels of the own points: 6 kx slabs of npts
+    double *Ob = nullptr;             // grid tendencies' results, all levels of the own points: 9 kx + nranks slabs of npts
+    double *Tb = nullptr;             // direct batches' outputs, all levels of the own coefficients: 9 kx + nranks slabs of ne
+    double *stage = nullptr;          // RCCL route: pack / unpack staging, (9 nl + 1) grids
 };
 
 #define NCCL_TRY(expr)                                                                                     \
@@ -117,6 +133,7 @@ void release_comms(spdy_plan *p)
         c->comm = nullptr;
         c->plan = nullptr;
         c->G = c->px = c->py = c->U = c->V = c->PL = c->T = c->tend = nullptr;     // plan-owned memory: gone with the plan
+        c->Gb = c->Ob = c->Tb = c->stage = nullptr;
     }
     p->comms.clear();
 }
@@ -225,6 +242,115 @@ int allgather_blocks(spdy_comm *c, int narr, double *const *d, const size_t *off
     return SPDY_OK;
 }
 
+/* Transposition between the two shardings of a level-block stack of F fields x levels (+ X level-free slabs per block;
+ * LevelShard, csrc/spdy_kernels.hpp):
+ *   by level : rank r holds ITS block -- nslab_r = F nl_r + X slabs -- over the whole horizontal domain (H doubles per slab);
+ *   by range : rank r holds ALL blocks over ITS horizontal range [h0[r], h0[r] + len[r]) of every slab.
+ * to_ranges: by level -> by range; otherwise back.  `lev` is the by-level array addressed like the whole stack (block r at slab
+ * slab0_r, pitch H); `rng` the by-range array with pitch rp doubles per slab: len[rank] for the compact range stacks, H for a
+ * whole array updated in place on a range (then rng == lev is allowed: what is read and what is written never overlap).
+ * In-process groups: every rank PULLS its pieces with 2-D device copies (the protocol of allgather_blocks).  RCCL: one grouped
+ * ncclSend / ncclRecv per peer on the plan's stream (graph-capturable) -- each rank's piece travels over its own xGMI link --
+ * with the strided side packed / unpacked through c->stage by 2-D copies; force >= 1 sends the rank's own piece through RCCL too
+ * (so that a 1-GPU box exercises the route).                                                                          */
+int transpose_blocks(spdy_comm *c, bool to_ranges, int F, int X, size_t H, const size_t *h0, const size_t *len, double *lev, double *rng, size_t rp)
+{
+    spdy_plan *p = c->plan;
+    if (c->dry) return SPDY_OK;
+    const int R = c->nranks, me = c->rank, kx = p->tab.kx;
+    std::vector<size_t> slab0(R), nslab(R);
+    for (int r = 0; r < R; ++r) {
+        int lo, hi;
+        level_range(kx, r, R, &lo, &hi);
+        slab0[r] = (size_t)F * lo + (size_t)X * r; nslab[r] = (size_t)F * (hi - lo) + X;
+    }
+    const size_t D = sizeof(double);
+    auto copy2d = [&](double *dst, size_t dpitch, const double *src, size_t spitch, size_t width, size_t height, int src_dev) -> hipError_t {
+        if (!width || !height) return hipSuccess;
+        (void)src_dev;      // (peer access is enabled both ways when a rank joins its group; unified addressing finds the device)
+        return hipMemcpy2DAsync(dst, dpitch * D, src, spitch * D, width * D, height, hipMemcpyDeviceToDevice, p->stream);
+    };
+    if (c->grp) {
+        spdy_comm_group *g = c->grp;
+        NOT_CAPTURING(p, "a collective of an in-process communicator (peer copies ordered by events of other ranks' streams)");
+        g->arr[0][me] = to_ranges ? lev : rng;
+        HIP_TRY_GROUP(g, hipEventRecord(g->ready[me], p->stream));
+        RC(group_barrier(g));
+        for (int q = 0; q < R; ++q) {
+            if (q != me) HIP_TRY_GROUP(g, hipStreamWaitEvent(p->stream, g->ready[q], 0));
+            const double *src = g->arr[0][q];
+            if (to_ranges)      // block q, my range: out of q's by-level array
+                HIP_TRY_GROUP(g, copy2d(rng + slab0[q] * rp, rp, src + slab0[q] * H + h0[me], H, len[me], nslab[q], g->device[q]));
+            else {              // my block, range q: out of q's by-range array (its pitch: compact = len[q], in place = H)
+                const size_t qp = rp == H ? H : len[q], qoff = rp == H ? h0[q] : 0;
+                if (q == me && rp == H && rng == lev) continue;             // in place: the own piece is where it belongs
+                HIP_TRY_GROUP(g, copy2d(lev + slab0[me] * H + h0[q], H, src + slab0[me] * qp + qoff, qp, len[q], nslab[me], g->device[q]));
+            }
+        }
+        HIP_TRY_GROUP(g, hipEventRecord(g->done[me], p->stream));
+        RC(group_barrier(g));
+        for (int q = 0; q < R; ++q)
+            if (q != me) HIP_TRY_GROUP(g, hipStreamWaitEvent(p->stream, g->done[q], 0));
+        return SPDY_OK;
+    }
+    // RCCL (one process per GPU)
+    const bool self_rccl = c->force >= 1;
+    if (R > 1 || self_rccl) {
+        if (!c->stage) return fail(SPDY_ERR_STATE, "no staging buffer (spdy_sharded_step_workspace)");
+    }
+    double *st = c->stage;
+    if (to_ranges) {
+        // pack: for every peer q the own block's slabs restricted to range q, contiguous [nslab_me][len_q] at st + nslab_me h0[q]
+        for (int q = 0; q < R; ++q) {
+            if (q == me && !self_rccl) HIP_TRY(copy2d(rng + slab0[me] * rp, rp, lev + slab0[me] * H + h0[me], H, len[me], nslab[me], p->device));
+            else HIP_TRY(copy2d(st + nslab[me] * h0[q], len[q], lev + slab0[me] * H + h0[q], H, len[q], nslab[me], p->device));
+        }
+        if (R > 1 || self_rccl) {
+            if (rp != len[me]) return fail(SPDY_ERR_ARG, "RCCL transposition to ranges needs a compact range stack");
+            NCCL_TRY(rccl().GroupStart());
+            for (int q = 0; q < R; ++q) {
+                if (q == me && !self_rccl) continue;
+                if (nslab[me] * len[q]) NCCL_GROUP_TRY(rccl().Send(st + nslab[me] * h0[q], nslab[me] * len[q], ncclDouble, q, c->comm, p->stream));
+                if (nslab[q] * len[me]) NCCL_GROUP_TRY(rccl().Recv(rng + slab0[q] * rp, nslab[q] * len[me], ncclDouble, q, c->comm, p->stream));
+            }
+            NCCL_TRY(rccl().GroupEnd());
+        }
+    } else {
+        const bool inplace = rp == H;
+        if (R > 1 || self_rccl) {
+            if (inplace)            // the by-range side is strided too: pack what every peer q gets (its block, my range) behind the receive area
+                for (int q = 0; q < R; ++q)
+                    if (q != me || self_rccl) HIP_TRY(copy2d(st + nslab[me] * H + slab0[q] * len[me], len[me], rng + slab0[q] * H + h0[me], H, len[me], nslab[q], p->device));
+            NCCL_TRY(rccl().GroupStart());
+            for (int q = 0; q < R; ++q) {
+                if (q == me && !self_rccl) continue;
+                const double *sendp = inplace ? st + nslab[me] * H + slab0[q] * len[me] : rng + slab0[q] * rp;
+                if (nslab[q] * len[me]) NCCL_GROUP_TRY(rccl().Send(sendp, nslab[q] * len[me], ncclDouble, q, c->comm, p->stream));
+                if (nslab[me] * len[q]) NCCL_GROUP_TRY(rccl().Recv(st + nslab[me] * h0[q], nslab[me] * len[q], ncclDouble, q, c->comm, p->stream));
+            }
+            NCCL_TRY(rccl().GroupEnd());
+        }
+        for (int q = 0; q < R; ++q) {       // unpack (own piece: straight from the by-range array unless it went through RCCL)
+            if (q == me && !self_rccl) {
+                if (!(inplace && rng == lev)) HIP_TRY(copy2d(lev + slab0[me] * H + h0[me], H, rng + slab0[me] * rp + (inplace ? h0[me] : 0), rp, len[me], nslab[me], p->device));
+            } else HIP_TRY(copy2d(lev + slab0[me] * H + h0[q], H, st + nslab[me] * h0[q], len[q], len[q], nslab[me], p->device));
+        }
+    }
+    return SPDY_OK;
+}
+
+// horizontal ranges of the transposed form, in units of the column kernels' 16-element blocks: [units r / R, units (r + 1) / R) x 16
+void block_ranges(size_t total, int R, size_t mult, std::vector<size_t> &h0, std::vector<size_t> &len)
+{
+    const size_t nblk = (total + 15) / 16;
+    h0.resize(R); len.resize(R);
+    for (int r = 0; r < R; ++r) {
+        const size_t b0 = nblk * r / R, b1 = nblk * (r + 1) / R;
+        const size_t e0 = std::min(total, b0 * 16), e1 = std::min(total, b1 * 16);
+        h0[r] = e0 * mult; len[r] = (e1 - e0) * mult;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -254,6 +380,7 @@ int spdy_comm_create(spdy_plan *p, int nranks, int rank, const char *id, spdy_co
     c->plan = p; c->nranks = nranks; c->rank = rank;
     if (const char *env = getenv("SPDY_COMM_FORCE")) c->force = atoi(env);
     if (const char *env = getenv("SPDY_COMM_DRY")) c->dry = atoi(env);
+    if (const char *env = getenv("SPDY_SHARD_TRANSPOSE")) c->transpose = atoi(env) != 0;
     ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
     if (r != ncclSuccess) {
         delete c;
@@ -344,6 +471,7 @@ int spdy_comm_create_local(spdy_plan *p, spdy_comm_group *g, int rank, spdy_comm
         }
     spdy_comm *c = new spdy_comm;
     c->plan = p; c->grp = g; c->nranks = g->nranks; c->rank = rank;
+    if (const char *env = getenv("SPDY_SHARD_TRANSPOSE")) c->transpose = atoi(env) != 0;
     g->member[rank] = c; g->device[rank] = p->device;
     ++g->attached;
     p->comms.push_back(c);
@@ -440,6 +568,54 @@ Shard shard_of(const spdy_comm *c)
     s.nl = s.hi - s.lo; s.gs = grid_elems(c->plan); s.ss = spec_elems(c->plan);
     return s;
 }
+// the transposed form's horizontal ranges: grid points (doubles) and spectral coefficients (in doubles: 2 per coefficient)
+struct Ranges { std::vector<size_t> g0, gl, s0, sl; };
+Ranges ranges_of(const spdy_comm *c)
+{
+    Ranges r;
+    block_ranges(grid_elems(c->plan), c->nranks, 1, r.g0, r.gl);
+    block_ranges(spec_elems(c->plan) / 2, c->nranks, 2, r.s0, r.sl);
+    return r;
+}
+/* All ranks end up with all ranges of the rows of `arr` ([nrows][H], every rank current on its own range [h0, h0 + len) of every
+ * row): the gather that makes a range-sharded array whole again.                                                          */
+int allgather_ranges(spdy_comm *c, double *arr, size_t nrows, size_t H, const size_t *h0, const size_t *len)
+{
+    spdy_plan *p = c->plan;
+    if (c->dry || !nrows) return SPDY_OK;
+    const int R = c->nranks, me = c->rank;
+    const size_t D = sizeof(double);
+    if (c->grp) {
+        spdy_comm_group *g = c->grp;
+        NOT_CAPTURING(p, "a collective of an in-process communicator (peer copies ordered by events of other ranks' streams)");
+        g->arr[0][me] = arr;
+        HIP_TRY_GROUP(g, hipEventRecord(g->ready[me], p->stream));
+        RC(group_barrier(g));
+        for (int q = 0; q < R; ++q) {
+            if (q == me || !len[q]) continue;
+            HIP_TRY_GROUP(g, hipStreamWaitEvent(p->stream, g->ready[q], 0));
+            HIP_TRY_GROUP(g, hipMemcpy2DAsync(arr + h0[q], H * D, g->arr[0][q] + h0[q], H * D, len[q] * D, nrows, hipMemcpyDeviceToDevice, p->stream));
+        }
+        HIP_TRY_GROUP(g, hipEventRecord(g->done[me], p->stream));
+        RC(group_barrier(g));
+        for (int q = 0; q < R; ++q)
+            if (q != me) HIP_TRY_GROUP(g, hipStreamWaitEvent(p->stream, g->done[q], 0));
+        return SPDY_OK;
+    }
+    if (R == 1 && !c->force) return SPDY_OK;
+    if (!c->stage) return fail(SPDY_ERR_STATE, "no staging buffer (spdy_sharded_step_workspace)");
+    // compact [nrows][len_q] pieces side by side in the staging buffer: piece q at nrows h0[q]; one broadcast per rank
+    double *st = c->stage;
+    HIP_TRY(hipMemcpy2DAsync(st + nrows * h0[me], len[me] * D, arr + h0[me], H * D, len[me] * D, nrows, hipMemcpyDeviceToDevice, p->stream));
+    NCCL_TRY(rccl().GroupStart());
+    for (int q = 0; q < R; ++q)
+        if (len[q]) NCCL_GROUP_TRY(rccl().Broadcast(st + nrows * h0[q], st + nrows * h0[q], nrows * len[q], ncclDouble, q, c->comm, p->stream));
+    NCCL_TRY(rccl().GroupEnd());
+    for (int q = 0; q < R; ++q)
+        if (q != me && len[q])
+            HIP_TRY(hipMemcpy2DAsync(arr + h0[q], H * D, st + nrows * h0[q], len[q] * D, len[q] * D, nrows, hipMemcpyDeviceToDevice, p->stream));
+    return SPDY_OK;
+}
 int need_sharded(spdy_comm *c)
 {
     spdy_plan *p = c->plan;
@@ -465,15 +641,57 @@ int spdy_sharded_step_workspace(spdy_comm *c)
     const Shard s = shard_of(c);
     const int kx = p->tab.kx;
     const size_t P = (size_t)3 * s.nl;
-    struct { double **dst; size_t n; } want[8] = {
-        {&c->G, (size_t)6 * kx * s.gs}, {&c->px, s.gs}, {&c->py, s.gs}, {&c->U, P * s.gs}, {&c->V, P * s.gs}, {&c->PL, (P + 1) * s.gs},
-        {&c->tend, (size_t)(4 * kx + 1) * s.ss}, {&c->T, (size_t)(9 * kx + c->nranks) * s.ss}};
+    const Ranges rg = ranges_of(c);
+    const size_t npts = rg.gl[c->rank], ned = rg.sl[c->rank];
+    // (U | V | PL are ONE allocation: the rank's block of the F = 9, X = 1 operand stack of the transposed form)
+    struct { double **dst; size_t n; } want[10] = {
+        {&c->G, (size_t)6 * kx * s.gs}, {&c->px, s.gs}, {&c->py, s.gs}, {&c->U, (3 * P + 1) * s.gs},
+        {&c->tend, (size_t)(4 * kx + 1) * s.ss}, {&c->T, (size_t)(9 * kx + c->nranks) * s.ss},
+        {&c->Gb, (size_t)6 * kx * npts}, {&c->Ob, (size_t)(9 * kx + c->nranks) * npts}, {&c->Tb, (size_t)(9 * kx + c->nranks) * ned},
+        {&c->stage, std::max((3 * P + 1) * s.gs, (size_t)(4 * kx + 2) * s.ss) + (size_t)(2 * kx + 2) * s.ss + (size_t)(9 * kx + c->nranks) * std::max(npts, ned)}};
     for (auto &w : want) {
         void *ptr;
-        RC(dev_alloc(p, w.n * sizeof(double), &ptr));
-        HIP_TRY(hipMemsetAsync(ptr, 0, w.n * sizeof(double), p->stream));
+        RC(dev_alloc(p, std::max<size_t>(w.n, 2) * sizeof(double), &ptr));
+        HIP_TRY(hipMemsetAsync(ptr, 0, std::max<size_t>(w.n, 2) * sizeof(double), p->stream));
         *w.dst = static_cast<double *>(ptr);
     }
+    c->V = c->U + P * s.gs;
+    c->PL = c->V + P * s.gs;
+    return SPDY_OK;
+}
+
+int spdy_comm_set_option(spdy_comm *c, const char *name, int value)
+{
+    NEED_COMM(c);
+    if (!name) return fail(SPDY_ERR_ARG, "null option name");
+    if (c->plan->capturing) return fail(SPDY_ERR_STATE, "communicator options cannot change while a graph capture is open");
+    const std::string n(name);
+    if (n == "transpose") {
+        if (c->ranges_valid && !value) return fail(SPDY_ERR_STATE, "the state is range-sharded: spdy_sharded_state_gather_dev first");
+        c->transpose = value != 0;
+    } else if (n == "force") c->force = value;
+    else if (n == "dry") c->dry = value;
+    else return fail(SPDY_ERR_ARG, "unknown communicator option '%s'", name);
+    return SPDY_OK;
+}
+
+int spdy_comm_describe(spdy_comm *c, char *buf, int len)
+{
+    NEED_COMM(c);
+    if (!buf || len < 1) return fail(SPDY_ERR_ARG, "null / empty buffer");
+    const Shard s = shard_of(c);
+    const Ranges rg = ranges_of(c);
+    const int kx = c->plan->tab.kx, R = c->nranks, me = c->rank;
+    // bytes this rank RECEIVES per step: the two all-gathers of the default form, the four exchanges of the transposed form
+    const double ag = (double)(R - 1) / R * 8.0 * ((double)6 * kx * s.gs + (double)(9 * kx + R) * s.ss) * (R > 1);   // (blocks of the other ranks; ~)
+    const double nl = s.nl;
+    const double tr = 8.0 * ((6.0 * (kx - nl)) * rg.gl[me] + (9 * nl + 1) * (double)(s.gs - rg.gl[me]) + (9.0 * (kx - nl) + (R - 1)) * rg.sl[me]
+                             + 4 * nl * (double)(s.ss - rg.sl[me]) + (double)(s.ss - rg.sl[me]));
+    snprintf(buf, (size_t)len, "{\"route\": \"%s\", \"librccl\": \"%s\", \"nranks\": %d, \"rank\": %d, \"form\": \"%s\", "
+             "\"levels\": [%d, %d], \"points\": [%zu, %zu], \"coefficients\": [%zu, %zu], "
+             "\"bytes_received_per_step_allgather_form\": %.0f, \"bytes_received_per_step_transposed_form\": %.0f}",
+             c->grp ? "in-process group (peer copies)" : "rccl", c->grp ? "" : rccl().path.c_str(), R, me, c->transpose ? "transpose" : "allgather",
+             s.lo, s.hi, rg.g0[me], rg.g0[me] + rg.gl[me], rg.s0[me] / 2, (rg.s0[me] + rg.sl[me]) / 2, ag, tr);
     return SPDY_OK;
 }
 
@@ -513,11 +731,36 @@ int spdy_sharded_step_grid_dev(spdy_comm *c, const double *vor, const double *di
     RC(spdy_sharded_step_workspace(c));
     const Shard s = shard_of(c);
     const int kx = p->tab.kx;
+    const Ranges rg = ranges_of(c);
+    if (c->transpose && c->ranges_valid) {
+        // Transposed form, exchange 4 (coefficient ranges -> levels), done where its result is first read: the previous step
+        // left the new prognostics on (all levels x own coefficients); this rank's inverse batch reads time level j2 of ITS
+        // levels at all coefficients, and the level-free ps whole.  In place in the caller's arrays (the part written here is
+        // exactly what this rank did not compute itself).
+        const size_t slot = (size_t)(j2 - 1) * kx * s.ss;
+        for (const double *arr : {vor, div, t, tr}) {
+            double *a2 = const_cast<double *>(arr) + slot;
+            RC(transpose_blocks(c, false, 1, 0, s.ss, rg.s0.data(), rg.sl.data(), a2, a2, s.ss));
+        }
+        RC(allgather_ranges(c, const_cast<double *>(ps) + (size_t)(j2 - 1) * s.ss, 1, s.ss, rg.s0.data(), rg.sl.data()));
+    }
     const size_t lev = (size_t)(j2 - 1) * kx * s.ss + (size_t)s.lo * s.ss;     // this rank's levels of time level j2
     double *Gb = c->G + (size_t)6 * s.lo * s.gs;                                // its block: ug | vg | vorg | divg | tg | trg, nl each
     const spdy_spec_seg segs[4] = {{s.nl, vor + lev}, {s.nl, div + lev}, {s.nl, t + lev}, {s.nl, tr + lev}};
     RC(spdy_inverse_batch_segs_dev(p, s.nl, vor + lev, div + lev, Gb, Gb + (size_t)s.nl * s.gs, 2, 4, segs, nullptr, 1,
                                    Gb + (size_t)2 * s.nl * s.gs, 1, ps + (size_t)(j2 - 1) * s.ss, c->px, c->py, 2));
+    if (c->transpose) {
+        // exchange 1 (levels -> point ranges), the grid tendencies of ALL levels on the own points, exchange 2 (back: every
+        // rank's direct-batch operands come home).  1 / R of the column kernel's work per rank, nothing replicated.
+        const int me = c->rank;
+        RC(transpose_blocks(c, true, 6, 0, s.gs, rg.g0.data(), rg.gl.data(), c->G, c->Gb, rg.gl[me]));
+        spdy::GridTend gt{c->Gb, c->Gb, c->Gb, c->Gb, c->Gb, c->Gb, c->px, c->py, c->U, c->V, c->PL, spdy::LevelShard{c->nranks, c->rank},
+                          (int)rg.gl[me], (int)rg.g0[me], c->Ob};
+        if (rg.gl[me]) KERNEL(spdy::launch_grid_tendencies(p->dev, gt, p->stream));
+        double *olev = c->U - ((size_t)9 * s.lo + me) * s.gs;                   // addressed like the whole operand stack: only the own block exists
+        RC(transpose_blocks(c, false, 9, 1, s.gs, rg.g0.data(), rg.gl.data(), olev, c->Ob, rg.gl[me]));
+        return SPDY_OK;
+    }
     std::vector<size_t> off(c->nranks), cnt(c->nranks);
     for (int r = 0; r < c->nranks; ++r) {
         int lo, hi;
@@ -546,9 +789,23 @@ int spdy_sharded_step_spectral_dev(spdy_comm *c, double *vor, double *div, doubl
     const int kx = p->tab.kx, P = 3 * s.nl;
     double *Tb = c->T + ((size_t)9 * s.lo + c->rank) * s.ss;                    // this rank's block: A | B | C (3 nl each) | psdt
     double *A = Tb, *B = Tb + (size_t)P * s.ss, *C = Tb + (size_t)2 * P * s.ss;
-    const bool raw = use_raw63(p, P);
+    const bool raw = !c->transpose && use_raw63(p, P);     // (transposed form: vds needs whole rows -- applied here, before the exchange)
     if (raw) RC(direct_batch_raw63(p, P, c->U, c->V, 2, P + 1, c->PL, C, A, B));
     else RC(spdy_direct_batch_dev(p, P, c->U, c->V, A, B, 2, P + 1, c->PL, C));
+    if (c->transpose) {
+        // exchange 3 (levels -> coefficient ranges), then the spectral step of ALL levels on the own coefficients.  The new state
+        // stays range-sharded: exchange 4 runs at the start of the next grid half (or spdy_sharded_state_gather_dev).
+        const Ranges rg = ranges_of(c);
+        const int me = c->rank;
+        RC(transpose_blocks(c, true, 9, 1, s.ss, rg.s0.data(), rg.sl.data(), c->T, c->Tb, rg.sl[me]));
+        if (!tend_out) tend_out = c->tend;
+        spdy::SpecStep a{c->Tb, c->Tb, c->Tb, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, sdrag, dt, eps, wil, j1,
+                         p->tab.ix == 4 * p->tab.iy, nullptr, nullptr, spdy::LevelShard{c->nranks, c->rank}, tend_out,
+                         (int)(rg.s0[me] / 2), (int)(rg.sl[me] / 2)};
+        if (rg.sl[me]) KERNEL(spdy::launch_spectral_step(p->dev, a, p->stream));
+        c->ranges_valid = c->nranks > 1;
+        return SPDY_OK;
+    }
     std::vector<size_t> off(c->nranks), cnt(c->nranks);
     for (int r = 0; r < c->nranks; ++r) {
         int lo, hi;
@@ -561,6 +818,38 @@ int spdy_sharded_step_spectral_dev(spdy_comm *c, double *vor, double *div, doubl
     spdy::SpecStep a{c->T, c->T, c->T, vor, div, t, tr, ps, phis, d_tcorh, d_qcorh, phi, sdrag, dt, eps, wil, j1,
                      p->tab.ix == 4 * p->tab.iy, raw ? c->T : nullptr, raw ? c->T : nullptr, spdy::LevelShard{c->nranks, c->rank}, tend_out};
     KERNEL(spdy::launch_spectral_step(p->dev, a, p->stream));
+    return SPDY_OK;
+}
+
+/* Every rank ends up with the complete arrays again: rows x (mx nx complex) arrays that the transposed form's spectral half
+ * left current on (all rows x own coefficients) only -- the prognostics (2 kx rows each; ps: 2), phi (kx), the final tendencies
+ * (4 kx + 1).  No-op for the all-gather form and for one rank.  Marks the state whole: the next grid half skips exchange 4.   */
+int spdy_sharded_gather_ranges_dev(spdy_comm *c, int narr, double *const *arr, const int *nrows)
+{
+    NEED_COMM(c);
+    spdy_plan *p = c->plan;
+    NEED_DEVICE(p);
+    if (narr < 0 || (narr && (!arr || !nrows))) return fail(SPDY_ERR_ARG, "bad argument");
+    if (!c->transpose || c->nranks == 1) return SPDY_OK;
+    RC(spdy_sharded_step_workspace(c));
+    const Shard s = shard_of(c);
+    const Ranges rg = ranges_of(c);
+    for (int a = 0; a < narr; ++a) {
+        if (!arr[a] || nrows[a] < 0 || nrows[a] > 4 * p->tab.kx + 2) return fail(SPDY_ERR_ARG, "array %d: null or more than 4 kx + 2 rows", a);
+        RC(allgather_ranges(c, arr[a], (size_t)nrows[a], s.ss, rg.s0.data(), rg.sl.data()));
+    }
+    return SPDY_OK;
+}
+
+int spdy_sharded_state_gather_dev(spdy_comm *c, double *vor, double *div, double *t, double *tr, double *ps)
+{
+    NEED_COMM(c);
+    if (!vor || !div || !t || !tr || !ps) return fail(SPDY_ERR_ARG, "null device pointer");
+    const int kx = c->plan->tab.kx;
+    double *arr[5] = {vor, div, t, tr, ps};
+    const int rows[5] = {2 * kx, 2 * kx, 2 * kx, 2 * kx, 2};
+    RC(spdy_sharded_gather_ranges_dev(c, 5, arr, rows));
+    c->ranges_valid = false;
     return SPDY_OK;
 }
 

@@ -194,6 +194,13 @@ struct GridTend {
     // the other five pointers are ignored) holding all levels; the outputs are this rank's own launch operands only --
     // u, v [3 nl], plain [3 nl + 1] with nl = the rank's level count (every rank gets the level-free last field)
     LevelShard sh;
+    // TRANSPOSED form of the level-sharded step (sh.nranks >= 1 and tr_out non-null): this rank holds ALL levels of the points
+    // [pt0, pt0 + npts) only.  `ug` is the F = 6 level-block stack with slabs of npts doubles (local point index); px, py stay
+    // whole grids (every rank computes them itself) and are read at pt0 + i; the outputs of ALL levels go to tr_out, an F = 9,
+    // X = 1 level-block stack with slabs of npts doubles -- block q = rank q's direct-batch operands u [3 nl_q] | v [3 nl_q] |
+    // plain [3 nl_q] | the level-free field, restricted to these points (u, v, plain are ignored).
+    int npts, pt0;
+    double *tr_out;
 };
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
 // Write-through policy of a model-sized launch (the step's kernels): outputs of at least p.lo.wt_min_mb MB (default 6; 0 = never)
@@ -217,6 +224,11 @@ struct SpecStep {
     // [vordt | divdt | tdt | trdt] (kx each) | psdt in the plain layout instead of back into the operands
     LevelShard sh;
     double *tend_out;
+    // TRANSPOSED form (sh.nranks >= 1 and ne > 0): this rank holds ALL levels of the coefficients [e0, e0 + ne) only (e0 a
+    // multiple of the kernel's 16-coefficient blocks).  The level-block stack `pvor` has slabs of ne complex values (local
+    // coefficient index); the prognostics, phi and tend_out are the whole arrays as ever and are read / written at these
+    // coefficients only.  No raw pairs (vds needs the neighbouring rows): raw_u must be null.
+    int e0, ne;
 };
 hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t s);
 // output path (input_output.f90:184-206)

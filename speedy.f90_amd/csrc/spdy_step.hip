@@ -362,11 +362,13 @@ template <int KM, bool FULL, bool SH, bool WT = false>
 __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, GridTend g)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int gsz = p.ix * p.il, kx = FULL ? KM : p.kx, tx = threadIdx.x, k = threadIdx.y;
+    // (TR, the transposed form of the sharded step: the slabs are this rank's npts points, global point = pt0 + i)
+    const bool TR = SH && g.tr_out != nullptr;
+    const int gsz = TR ? g.npts : p.ix * p.il, kx = FULL ? KM : p.kx, tx = threadIdx.x, k = threadIdx.y;
     constexpr int BX = GT_BX;                                              // grid points per block
     const int i0 = blockIdx.x * BX + tx;
     const bool valid = i0 < gsz;
-    const int i = valid ? i0 : gsz - 1, j = i / p.ix;
+    const int i = valid ? i0 : gsz - 1, ig = TR ? g.pt0 + i : i, j = ig / p.ix;
     double *su = sm, *sv = sm + kx * BX, *st = sm + 2 * kx * BX, *sq = sm + 3 * kx * BX, *sp = sm + 4 * kx * BX, *sd = sm + 5 * kx * BX;
     double *ssig = sm + 6 * kx * BX, *ssigm = ssig + (kx + 1) * BX, *smean = ssigm + (kx + 1) * BX;   // smean: umean, vmean, dmean rows
     double *stab = smean + 3 * BX;                                                                    // dhs[kx]
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
     int og = kx, ok = k, o_ps = 3 * kx;                                    // output group stride, level slot, slot of the level-free field
     bool own = true;
     double ug_c, vg_c, tg_c, tr_c, dv, vor_in;
+    double *out_u = g.u, *out_v = g.v, *out_pl = g.plain;
     if (SH) {
         const LevelBlock b = level_block(k, kx, g.sh.nranks);
         const long s0 = (long)6 * b.lo + (k - b.lo);                       // slab of (field 0, level k) in the F = 6 block stack
@@ -383,11 +386,15 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
         tg_c = LV(g.ug, s0 + 4 * b.nl); tr_c = LV(g.ug, s0 + 5 * b.nl);
         const int lo = (kx * g.sh.rank) / g.sh.nranks, hi = (kx * (g.sh.rank + 1)) / g.sh.nranks;
         og = hi - lo; ok = k - lo; o_ps = 3 * og; own = k >= lo && k < hi;
+        if (TR) {       // every level's results, into the block of the level's OWNER: u | v | plain (3 nl each) | the level-free field
+            out_u = g.tr_out + ((long)9 * b.lo + b.r) * gsz; out_v = out_u + (long)3 * b.nl * gsz; out_pl = out_v + (long)3 * b.nl * gsz;
+            og = b.nl; ok = k - b.lo; own = true;
+        }
     } else {
         ug_c = LV(g.ug, k); vg_c = LV(g.vg, k); tg_c = LV(g.tg, k); tr_c = LV(g.trg, k); dv = LV(g.divg, k); vor_in = LV(g.vorg, k);
     }
     const double vor = vor_in + p.coriol[j];                                               // (:103-107 coriolis)
-    const double px = g.px[i], py = g.py[i], rgas = p.rgas, akap = p.akap;
+    const double px = g.px[ig], py = g.py[ig], rgas = p.rgas, akap = p.akap;
     const double dhr = p.dhsr[k], trefk = p.tref[k];
     const double tgg = tg_c - trefk;                                                       // (:149)
     if (tx == 0) stab[k] = p.dhs[k];
@@ -425,7 +432,12 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
     }
     lds_sync();
     if (!valid) return;
-    if (k == 0) g.plain[(long)o_ps * gsz + i] = (-umean) * px - vmean * py;                // (:125)
+    if (TR) {           // the level-free field goes into EVERY rank's block (level row q writes rank q's copy)
+        if (k < g.sh.nranks) {
+            const int lo_q = (kx * k) / g.sh.nranks, nl_q = (kx * (k + 1)) / g.sh.nranks - lo_q;
+            g.tr_out[((long)9 * lo_q + k + 9 * nl_q) * gsz + i] = (-umean) * px - vmean * py;
+        }
+    } else if (k == 0) g.plain[(long)o_ps * gsz + i] = (-umean) * px - vmean * py;         // (:125)
     if (SH && !own) return;
     const double sig = S(ssig, k), sig1 = S(ssig, k + 1), sigm = S(ssigm, k), sigm1 = S(ssigm, k + 1);
     // fluxes temp(k) and temp(k+1) of the advected quantities (zero at the top level 1 and at kx+1: :152-153)
@@ -446,14 +458,14 @@ __global__ __launch_bounds__(GT_BX * KM) void grid_tendencies_kernel(DevPlan p, 
     }
     // (WT: a launch with several MB of output writes it through, launch_grid_tendencies)
 #define GT_ST(a_, k_, v_) do { if (WT) st1_wt(&LV(a_, k_), (v_)); else LV(a_, k_) = (v_); } while (0)
-    GT_ST(g.u, ok, vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr);                       // utend (:160-161)
-    GT_ST(g.v, ok, -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr);                      // vtend (:170-171)
-    GT_ST(g.plain, og + ok, tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
+    GT_ST(out_u, ok, vg_c * vor - tgg * rgas * px - (tu1 + tu) * dhr);                       // utend (:160-161)
+    GT_ST(out_v, ok, -ug_c * vor - tgg * rgas * py - (tv1 + tv) * dhr);                      // vtend (:170-171)
+    GT_ST(out_pl, og + ok, tgg * dv - (tt1 + tt) * dhr + p.fsgr[k] * tgg * (sig1 + sig) + p.tref3[k] * (sigm1 + sigm)
                             + akap * (tg_c * puv - tgg * dmean));                          // ttend (:181-184)
-    GT_ST(g.plain, 2 * og + ok, tr_c * dv - (tq1 + tq) * dhr);                             // trtend (:194)
-    GT_ST(g.plain, ok, 0.5 * (ug_c * ug_c + vg_c * vg_c));                                 // kinetic energy (:220)
-    GT_ST(g.u, og + ok, -ug_c * tgg);  GT_ST(g.v, og + ok, -vg_c * tgg);                   // (:224)
-    GT_ST(g.u, 2 * og + ok, -ug_c * tr_c);  GT_ST(g.v, 2 * og + ok, -vg_c * tr_c);         // (:229)
+    GT_ST(out_pl, 2 * og + ok, tr_c * dv - (tq1 + tq) * dhr);                             // trtend (:194)
+    GT_ST(out_pl, ok, 0.5 * (ug_c * ug_c + vg_c * vg_c));                                 // kinetic energy (:220)
+    GT_ST(out_u, og + ok, -ug_c * tgg);  GT_ST(out_v, og + ok, -vg_c * tgg);                   // (:224)
+    GT_ST(out_u, 2 * og + ok, -ug_c * tr_c);  GT_ST(out_v, 2 * og + ok, -vg_c * tr_c);         // (:229)
 #undef GT_ST
 #undef LV
 #undef S
@@ -466,7 +478,9 @@ hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream
     if (g.sh.nranks >= 1 && (p.kx > 16 || g.sh.nranks > p.kx || g.sh.rank < 0 || g.sh.rank >= g.sh.nranks)) return hipErrorInvalidValue;
     if (p.kx > 16) hipLaunchKernelGGL(grid_tendencies_serial_kernel, dim3((gsz + 63) / 64), dim3(64), 0, s, p, g);
     else if (g.sh.nranks >= 1) {
-        const dim3 grd((gsz + GT_BX - 1) / GT_BX), blk(GT_BX, p.kx);
+        if (g.tr_out && (g.npts <= 0 || g.pt0 < 0 || g.pt0 + g.npts > gsz)) return hipErrorInvalidValue;
+        const int npts = g.tr_out ? g.npts : gsz;
+        const dim3 grd((npts + GT_BX - 1) / GT_BX), blk(GT_BX, p.kx);
         const size_t lds = grid_tendencies_lds(p.kx, GT_BX);
         if (p.kx == 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, true, true>), grd, blk, lds, s, p, g);
         else if (p.kx < 8) hipLaunchKernelGGL((grid_tendencies_kernel<8, false, true>), grd, blk, lds, s, p, g);
@@ -538,9 +552,14 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     extern __shared__ __attribute__((aligned(16))) double sm[];           // complex planes [kx][64]: divdt, tdt, phi / yf / d, div, t; + rows
     const int kx = FULL ? 2 * NJ : p.kx, sz = p.mx * p.nx, tx = threadIdx.x, k = threadIdx.y;
     constexpr int BX = STEP_BX;                                            // coefficients per block: LDS offsets are immediates
-    const int e = blockIdx.x * BX + tx;
-    const bool valid = e < sz;
-    const int ec = valid ? e : sz - 1, m = ec % p.mx, n = ec / p.mx, l = m + n;
+    // (TR, the transposed form of the sharded step: the blocks of this launch are the coefficients [e0, e0 + ne); the level-block
+    // stack has slabs of ne values and is indexed with es = e - e0, everything else with the global e as ever)
+    const bool TR = SH && a.ne > 0;
+    const int e = (TR ? a.e0 : 0) + blockIdx.x * BX + tx, e_end = TR ? a.e0 + a.ne : sz;
+    const bool valid = e < e_end;
+    const int ec = valid ? e : e_end - 1, m = ec % p.mx, n = ec / p.mx, l = m + n;
+    const int es = TR ? ec - a.e0 : ec;                                    // index into the direct batches' outputs
+    const long ssz = TR ? a.ne : sz;                                       // ... and their slab size
     const long i = (long)k * sz + ec;                                     // this thread's (level, coefficient)
     const size_t PL = (size_t)kx * 2 * BX;                                 // doubles per complex plane [kx][BX]
     double *sdiv = sm, *stdt = sm + PL, *sy = sm + 2 * PL;
@@ -558,12 +577,12 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
     // the direct batch's outputs: group f of stack X (A = pvor / raw_u, B = pdiv / raw_v, C = pspec) at this thread's level is
     // element  (lv + f * L) + off_X  of pointer p_X.  Plain layout: three stacks [3 kx] with their own pointers.  Level-block
     // layout: one pointer, block of this level's owner = [A | B | C] (3 nl each) + its copy of the level-free psdt.
-    long lv = (long)k * sz, L = (long)kx * sz, offB = 0, offC = 0, ipsdt = (long)3 * kx * sz + ec;
+    long lv = (long)k * sz, L = (long)kx * sz, offB = 0, offC = 0, ipsdt = (long)3 * kx * sz + es;
     const double *pA = a.raw_u ? a.raw_u : a.pvor, *pB = a.raw_u ? a.raw_v : a.pdiv, *pC = a.pspec;
     if (SH) {
         const LevelBlock b = level_block(k, kx, a.sh.nranks);
-        lv = ((long)9 * b.lo + b.r + (k - b.lo)) * sz; L = (long)b.nl * sz; offB = 3 * L; offC = 6 * L;
-        ipsdt = (long)9 * (kx / a.sh.nranks) * sz + ec;                   // block 0 = [9 nl_0] + psdt, nl_0 = floor(kx / R)
+        lv = ((long)9 * b.lo + b.r + (k - b.lo)) * ssz; L = (long)b.nl * ssz; offB = 3 * L; offC = 6 * L;
+        ipsdt = (long)9 * (kx / a.sh.nranks) * ssz + es;                  // block 0 = [9 nl_0] + psdt, nl_0 = floor(kx / R)
         pA = pB = pC = a.pvor;
     }
     const cpx ps2 = ld(a.ps, sz + ec), phs = ld(a.phis, ec), psdt_in = ld(pC, ipsdt);
@@ -574,7 +593,7 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         // transform kernel does not apply it): the expressions of vds_kernel (spdy_kernels.hip), row by row.  Every load is
         // unconditional at a clamped row; the rows the reference special-cases only choose among loaded values.
         const int nm = max(n - 1, 0), np = min(n + 1, p.nx - 1);
-        const long i0 = lv + ec, rm = lv + nm * p.mx + m, rp = lv + np * p.mx + m;
+        const long i0 = lv + es, rm = lv + nm * p.mx + m, rp = lv + np * p.mx + m;      // (never TR: launch_spectral_step)
         const double gx = p.gradx[m], dm = p.vddym[ec], dp = p.vddyp[ec];
         const cpx u0 = ld(pA, i0), u0m = ld(pA, rm), u0p = ld(pA, rp);
         const cpx v0 = ld(pB, offB + i0), v0m = ld(pB, offB + rm), v0p = ld(pB, offB + rp);
@@ -595,14 +614,14 @@ __device__ __forceinline__ void spectral_step_body(const DevPlan &p, const SpecS
         pd1 = vds_div(v1m, v1p, u1);
         pd2 = vds_div(v2m, v2p, u2);
     } else {
-        vordt = ld(pA, lv + ec);
-        pd0 = ld(pB, offB + lv + ec);
-        pd1 = ld(pB, offB + L + lv + ec);
-        pd2 = ld(pB, offB + 2 * L + lv + ec);
+        vordt = ld(pA, lv + es);
+        pd0 = ld(pB, offB + lv + es);
+        pd1 = ld(pB, offB + L + lv + es);
+        pd2 = ld(pB, offB + 2 * L + lv + es);
     }
-    cpx divdt = pd0 - p.el2[ec] * (-ld(pC, offC + lv + ec));
-    cpx tdt = pd1 + ld(pC, offC + L + lv + ec);
-    cpx trdt = pd2 + ld(pC, offC + 2 * L + lv + ec);
+    cpx divdt = pd0 - p.el2[ec] * (-ld(pC, offC + lv + es));
+    cpx tdt = pd1 + ld(pC, offC + L + lv + es);
+    cpx trdt = pd2 + ld(pC, offC + 2 * L + lv + es);
     // ---- get_spectral_tendencies (time level 1 of div, t, ps).  Every thread brings its own level of div and t into LDS (one
     // coalesced global round trip for the block); the three level recurrences -- vertical mean, sigma-dot prefix sum, the
     // hydrostatic integration -- are then short loops over LDS by ONE wave each (k = 0 and k = 1 run them side by side),
@@ -837,9 +856,13 @@ hipError_t launch_spectral_step(const DevPlan &p, const SpecStep &a, hipStream_t
     if (p.kx > 16) return hipErrorInvalidValue;
     const int bx = spectral_step_bx(p);
     const size_t lds = spectral_step_lds(p.kx, bx);
-    const dim3 grd((sz + bx - 1) / bx), blk(bx, p.kx);
+    dim3 grd((sz + bx - 1) / bx), blk(bx, p.kx);
     if (a.sh.nranks >= 1) {
         if (a.sh.nranks > p.kx || !a.tend_out) return hipErrorInvalidValue;
+        if (a.ne > 0) {                                                    // transposed form: this rank's coefficient range only
+            if (a.raw_u || a.e0 < 0 || a.e0 % bx || a.e0 + a.ne > sz) return hipErrorInvalidValue;
+            grd = dim3((a.ne + bx - 1) / bx);
+        }
         if (p.kx == 8) hipLaunchKernelGGL((spectral_step_kernel<4, true, true>), grd, blk, lds, s, p, a);
         else if (p.kx < 8) hipLaunchKernelGGL((spectral_step_kernel<4, false, true>), grd, blk, lds, s, p, a);
         else if (p.kx == 16) hipLaunchKernelGGL((spectral_step_kernel<8, true, true>), grd, blk, lds, s, p, a);

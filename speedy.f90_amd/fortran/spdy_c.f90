@@ -272,6 +272,33 @@ module spdy_c
             type(c_ptr), value :: graph
             integer(c_int) :: rc
         end function
+        function spdy_comm_set_option(comm, name, value) bind(C, name="spdy_comm_set_option") result(rc)
+            import :: c_char, c_int, c_ptr
+            type(c_ptr), value :: comm
+            character(kind=c_char), intent(in) :: name(*)     ! NUL-terminated
+            integer(c_int), value :: value
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_state_gather_dev(comm, vor, div, t, tr, ps) bind(C, name="spdy_sharded_state_gather_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm, vor, div, t, tr, ps
+            integer(c_int) :: rc
+        end function
+        function spdy_sharded_gather_ranges_dev(comm, narr, arrays, nrows) bind(C, name="spdy_sharded_gather_ranges_dev") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: comm
+            integer(c_int), value :: narr
+            type(c_ptr), intent(in) :: arrays(*)
+            integer(c_int), intent(in) :: nrows(*)
+            integer(c_int) :: rc
+        end function
+        function spdy_comm_describe(comm, buf, len) bind(C, name="spdy_comm_describe") result(rc)
+            import :: c_char, c_int, c_ptr
+            type(c_ptr), value :: comm
+            character(kind=c_char), intent(out) :: buf(*)
+            integer(c_int), value :: len
+            integer(c_int) :: rc
+        end function
         function spdy_graph_num_nodes(graph, nodes) bind(C, name="spdy_graph_num_nodes") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: graph

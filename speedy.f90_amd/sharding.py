@@ -169,6 +169,36 @@ class LevelComm:
         return (torch.as_tensor(_DevArray(g.value, (gn.value,), "<f8"), device=dev),
                 torch.as_tensor(_DevArray(t.value, (tn.value,), "<f8"), device=dev))
 
+    # ---- the transposed form (levels <-> point / coefficient ranges; include/spdy.h)
+    def set_option(self, name, value):
+        """spdy_comm_set_option: "transpose" 0 | 1 selects the form of the sharded step; "force", "dry" as the environment."""
+        from ._lib import check
+        check(self.sp.lib.spdy_comm_set_option(self.h, name.encode(), int(value)))
+
+    def state_gather_(self, vor, div, t, tr, ps):
+        """Transposed form: make the prognostic arrays whole on every rank again (spdy_sharded_state_gather_dev)."""
+        from ._lib import check
+        self.sp._sync_stream()
+        check(self.sp.lib.spdy_sharded_state_gather_dev(self.h, vor.data_ptr(), div.data_ptr(), t.data_ptr(), tr.data_ptr(), ps.data_ptr()))
+
+    def gather_ranges_(self, *arrays):
+        """Transposed form: complete arrays of [rows, nx, mx] complex values that a step left current on this rank's coefficients
+        only (phi, the final tendencies)."""
+        import ctypes
+        from ._lib import check
+        self.sp._sync_stream()
+        arr = (ctypes.c_void_p * len(arrays))(*[a.data_ptr() for a in arrays])
+        rows = (ctypes.c_int * len(arrays))(*[int(a.numel() // (self.sp.nx * self.sp.mx)) for a in arrays])
+        check(self.sp.lib.spdy_sharded_gather_ranges_dev(self.h, len(arrays), arr, rows))
+
+    def describe(self):
+        """spdy_comm_describe as a dict: route / librccl path, ranks, form, this rank's shares, bytes received per step."""
+        import ctypes, json
+        from ._lib import check
+        buf = ctypes.create_string_buffer(2048)
+        check(self.sp.lib.spdy_comm_describe(self.h, buf, 2048))
+        return json.loads(buf.value.decode())
+
     def close(self):
         if self.h:
             self.sp.lib.spdy_comm_destroy(self.h)

@@ -68,7 +68,7 @@ def unsharded_device_steps(sp, st, nsteps):
     return out
 
 
-def _rank_thread(rank, group, tag, st, nsteps, results, errors, device=0):
+def _rank_thread(rank, group, tag, st, nsteps, results, errors, device=0, transpose=False):
     import torch
     import speedy_f90_amd as s
     try:
@@ -76,6 +76,8 @@ def _rank_thread(rank, group, tag, st, nsteps, results, errors, device=0):
         sp = make_plan(tag, device)
         sp.use_own_stream()
         comm = s.sharding.LevelComm(sp, group=group, rank=rank)
+        if transpose:
+            comm.set_option("transpose", 1)
         comm.sharded_step_workspace()
         kx, nx, mx = sp.kx, sp.nx, sp.mx
         D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
@@ -95,7 +97,18 @@ def _rank_thread(rank, group, tag, st, nsteps, results, errors, device=0):
                                             WIL, phi, tend)
             sp.synchronize()
         U, V, PL, lo, hi = comm.sharded_step_operands()
-        out = {n: D[n].cpu().numpy() for n in PROGS}
+        out = {}
+        if transpose:
+            # what the rank holds BEFORE the gather: its coefficient range of every level is current (both time levels)
+            desc = comm.describe()
+            e0, e1 = desc["coefficients"]
+            out["own_range"] = (e0, e1)
+            out["before"] = {n: D[n].reshape(D[n].shape[:-2] + (-1,))[..., e0:e1].cpu().numpy() for n in PROGS}
+            out["describe"] = desc
+            comm.state_gather_(D["vor"], D["div"], D["t"], D["tr"], D["ps"])
+            comm.gather_ranges_(phi, tend)
+            sp.synchronize()
+        out.update({n: D[n].cpu().numpy() for n in PROGS})
         out.update(phi=phi.cpu().numpy(), tend=tend.cpu().numpy(), U=U.cpu().numpy(), V=V.cpu().numpy(), PL=PL.cpu().numpy(), lo=lo, hi=hi)
         results[rank] = out
         comm.close(); sp.close()
@@ -149,6 +162,81 @@ def test_sharded_step_in_process_ranks(tag, world, oracle_factory, monkeypatch):
         assert np.array_equal(got["PL"], np.concatenate([whole["PL"][own], whole["PL"][3 * kx:]]))
     print("\n[sharded step %s, %d in-process ranks] worst relative error vs the oracle %.1e; bits equal to the unsharded device step"
           % (tag, world, worst))
+    assert worst <= TOL, (tag, world, worst)
+
+
+@pytest.mark.parametrize("tag,world", [(t, w) for t in ("t30", "t30k5", "t63k16") for w in (1, 2, 3)] + [("t30", 8), ("t63k16", 8)])
+def test_sharded_step_transposed_in_process_ranks(tag, world, oracle_factory, monkeypatch):
+    """The TRANSPOSED form of the level-sharded step (spdy_comm_set_option "transpose"; include/spdy.h): levels <-> point ranges
+    around the grid-space column kernel, levels <-> coefficient ranges around the spectral step (tendencies.f90:109-197, 242-293,
+    implicit.f90:168-217 are independent in the horizontal), four exchanges instead of two all-gathers, nothing replicated.
+    Real multi-rank runs with in-process ranks on one GPU, two chained steps (the second one starts with exchange 4 in the
+    caller's arrays), then the state gather.  Against the oracle's call-by-call step at 1e-12; against the unsharded device step
+    BIT FOR BIT at T30 (same kernels' expressions on the same values, whatever the rank count) and to rounding at T63 L16 (there
+    the unsharded step applies vds inside the spectral step, the transposed form before its exchange)."""
+    import speedy_f90_amd as s
+    monkeypatch.setenv("SPDY_COMM_TIMEOUT_S", "60")
+    kx = VARIANTS[tag][3]
+    o = oracle_factory(tag)
+    o.tail_init(DT)
+    sp0 = make_plan(tag)
+    st = state(sp0, 8000)
+    nsteps = 2
+    whole = unsharded_device_steps(sp0, st, nsteps)
+    group = s.sharding.LocalGroup(sp0.lib, world)
+    results, errors = {}, {}
+    threads = [threading.Thread(target=_rank_thread, args=(r, group, tag, st, nsteps, results, errors, 0, True)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    assert sorted(results) == list(range(world))
+    group.close(); sp0.close()
+    ref = st
+    for _ in range(nsteps):
+        ref, out = oracle_dynamics_step(o, ref, 2, DT, ROB)
+    ref_tend = np.concatenate([out["vordt"], out["divdt"], out["tdt"], out["trdt"], out["psdt"][None]])
+    exact = tag.startswith("t30")
+    worst, covered = 0.0, 0
+    for r in range(world):
+        got = results[r]
+        own = [g * kx + k for g in range(3) for k in range(got["lo"], got["hi"])]
+        for n in PROGS:
+            worst = max(worst, synth.relerr(got[n], ref[n]), wave_relerr(got[n], ref[n]))
+        worst = max(worst, wave_relerr(got["phi"], out["phi"]))
+        for a in range(4):
+            worst = max(worst, wave_relerr(got["tend"][a * kx:(a + 1) * kx], ref_tend[a * kx:(a + 1) * kx]))
+        worst = max(worst, synth.relerr(got["tend"][4 * kx], ref_tend[4 * kx]))
+        worst = max(worst, synth.relerr(got["U"], out["U"][own]), synth.relerr(got["V"], out["V"][own]),
+                    synth.relerr(got["PL"], np.concatenate([out["PL"][own], out["PL"][3 * kx:]])))
+        # the ranks' coefficient ranges tile the spectrum, and each rank's range was current before the gather
+        e0, e1 = got["own_range"]
+        covered += e1 - e0
+        for n in PROGS:
+            flat = whole[n].reshape(whole[n].shape[:-2] + (-1,))[..., e0:e1]
+            if exact:
+                assert np.array_equal(got["before"][n], flat), (tag, world, r, n)
+            else:
+                assert synth.relerr(got["before"][n], flat) <= 1e-13, (tag, world, r, n)
+        for n in PROGS + ("phi", "tend"):
+            if exact:
+                assert np.array_equal(got[n], whole[n]), (tag, world, r, n, synth.relerr(got[n], whole[n]))
+            else:
+                assert synth.relerr(got[n], whole[n]) <= 1e-13, (tag, world, r, n, synth.relerr(got[n], whole[n]))
+        # the direct-batch operands of the rank's levels came home complete (exchange 2)
+        wpl = np.concatenate([whole["PL"][own], whole["PL"][3 * kx:]])
+        if exact:
+            assert np.array_equal(got["U"], whole["U"][own]) and np.array_equal(got["V"], whole["V"][own]) and np.array_equal(got["PL"], wpl)
+        else:   # (second step: its inputs already differ by the first step's rounding)
+            assert max(synth.relerr(got["U"], whole["U"][own]), synth.relerr(got["V"], whole["V"][own]), synth.relerr(got["PL"], wpl)) <= 1e-13
+        d = got["describe"]
+        assert d["form"] == "transpose" and d["nranks"] == world and d["rank"] == r
+        if world >= 4:      # (at two ranks the four exchanges move about what the two all-gathers do; the form pays from four ranks on)
+            assert d["bytes_received_per_step_transposed_form"] < 0.6 * d["bytes_received_per_step_allgather_form"], d
+    assert covered == results[0]["vor"].shape[-1] * results[0]["vor"].shape[-2]
+    print("\n[transposed sharded step %s, %d in-process ranks] worst relative error vs the oracle %.1e; %s the unsharded device step"
+          % (tag, world, worst, "bits equal to" if exact else "within 1e-13 of"))
     assert worst <= TOL, (tag, world, worst)
 
 
