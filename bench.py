@@ -655,6 +655,11 @@ def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
     sp.initialize_implicit(2400.0)
     comm = s.sharding.LevelComm(sp)
     out["rccl_ranks"] = comm.world
+    # which librccl the C ABI bound its symbols from (a process carrying two RCCL builds is a known source of hangs), the rank
+    # count RCCL's communicator was built with, and what one rank receives per step in either form of the sharded step
+    out["comm"] = comm.describe()
+    out["librccl"] = out["comm"].get("librccl")
+    out["n_ranks_seen_by_rccl"] = out["comm"].get("nranks")
     lo, hi = comm.level_range(kx)
     nl = hi - lo
     out["levels_per_rank"] = [s.sharding.shard_range(kx, r, world)[1] - s.sharding.shard_range(kx, r, world)[0] for r in range(world)]
@@ -698,20 +703,37 @@ def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
         with sp.graph_capture() as g:
             for _ in range(per_graph):
                 c.sharded_step_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, 2, 2400.0, ROB, WIL, D["phi"])
+        nodes = g.num_nodes()
         us = timed(g.launch, reps=max(5, 40 // per_graph), warm=3) / per_graph    # (a few dozen leapfrog steps of a seeded state: stays finite)
         g.close()
-        return us, D
-    us_with, D = replay_us(comm)
+        return us, D, nodes
+    us_with, D, nodes_ag = replay_us(comm)
     try:        # eight steps per graph launch: a graph launch's own start-up latency (4-6 us) off seven steps of eight
-        us_with8, _ = replay_us(comm, per_graph=8)
+        us_with8, _, _ = replay_us(comm, per_graph=8)
     except Exception as e:
         us_with8 = repr(e)
     finite = bool(torch.isfinite(torch.view_as_real(D["vor"])).all().item())
     os.environ["SPDY_COMM_DRY"] = "1"
     dry = s.sharding.LevelComm(sp)
     os.environ.pop("SPDY_COMM_DRY")
-    us_dry, _ = replay_us(dry)
+    us_dry, _, _ = replay_us(dry)
     dry.close()
+    # the TRANSPOSED form of the same step (levels <-> point / coefficient ranges: four grouped send/recv exchanges, 1 / R of the
+    # column kernels per rank, nothing replicated) on a communicator of its own
+    transposed = {}
+    try:
+        os.environ["SPDY_SHARD_TRANSPOSE"] = "1"
+        tc = s.sharding.LevelComm(sp)
+        os.environ.pop("SPDY_SHARD_TRANSPOSE")
+        us_t, Dt, nodes_t = replay_us(tc)
+        tc.state_gather_(Dt["vor"], Dt["div"], Dt["t"], Dt["tr"], Dt["ps"])
+        sp.synchronize()
+        transposed = {"us_with_exchanges": us_t, "graph_nodes": nodes_t, "comm": tc.describe(),
+                      "state_finite_after_replays_and_gather": bool(torch.isfinite(torch.view_as_real(Dt["vor"])).all().item())}
+        tc.close()
+    except Exception as e:
+        os.environ.pop("SPDY_SHARD_TRANSPOSE", None)
+        transposed = {"error": repr(e)}
     # the unsharded step of one GPU on the same state (every rank runs it; identical work)
     D = fresh()
     P = 3 * kx
@@ -731,7 +753,10 @@ def multi_gpu_report(s, torch, synth, sp, dev, rank, world):
     out["sharded_step"] = {"us_with_exchanges": us_with, "us_with_exchanges_eight_per_graph": us_with8, "us_without_exchanges": us_dry, "us_unsharded": us_whole,
                            "state_finite_after_replays": finite,
                            "transforms_per_rank": (6 * nl + 2, 9 * nl + 1), "exchange_bytes_per_rank": (6 * nl * gs, (9 * nl + 1) * ss),
-                           "exchange_bytes_total": (6 * kx * gs, (9 * kx + world) * ss), "launches_in_graph": "4 kernels + 2 all-gathers",
+                           "exchange_bytes_total": (6 * kx * gs, (9 * kx + world) * ss), "launches_in_graph": nodes_ag,
+                           "bytes_received_per_rank_per_step": {"allgather_form": out["comm"].get("bytes_received_per_step_allgather_form"),
+                                                                "transposed_form": out["comm"].get("bytes_received_per_step_transposed_form")},
+                           "transposed_form": transposed,
                            "note": "complete adiabatic step, transforms sharded by level, both level exchanges inside the graph; "
                                    "max over ranks of graph-replay time"}
     comm.close()

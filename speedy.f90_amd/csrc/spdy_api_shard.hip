@@ -732,7 +732,9 @@ int spdy_sharded_step_grid_dev(spdy_comm *c, const double *vor, const double *di
     const Shard s = shard_of(c);
     const int kx = p->tab.kx;
     const Ranges rg = ranges_of(c);
-    if (c->transpose && c->ranges_valid) {
+    // (inside a graph capture the exchange is always recorded: a replayed step follows a transposed step; on a whole state it
+    // moves values that are already there)
+    if (c->transpose && (c->ranges_valid || p->capturing) && (c->nranks > 1 || c->force)) {
         // Transposed form, exchange 4 (coefficient ranges -> levels), done where its result is first read: the previous step
         // left the new prognostics on (all levels x own coefficients); this rank's inverse batch reads time level j2 of ITS
         // levels at all coefficients, and the level-free ps whole.  In place in the caller's arrays (the part written here is
@@ -803,7 +805,7 @@ int spdy_sharded_step_spectral_dev(spdy_comm *c, double *vor, double *div, doubl
                          p->tab.ix == 4 * p->tab.iy, nullptr, nullptr, spdy::LevelShard{c->nranks, c->rank}, tend_out,
                          (int)(rg.s0[me] / 2), (int)(rg.sl[me] / 2)};
         if (rg.sl[me]) KERNEL(spdy::launch_spectral_step(p->dev, a, p->stream));
-        c->ranges_valid = c->nranks > 1;
+        c->ranges_valid = c->nranks > 1 || c->force;
         return SPDY_OK;
     }
     std::vector<size_t> off(c->nranks), cnt(c->nranks);
@@ -830,7 +832,7 @@ int spdy_sharded_gather_ranges_dev(spdy_comm *c, int narr, double *const *arr, c
     spdy_plan *p = c->plan;
     NEED_DEVICE(p);
     if (narr < 0 || (narr && (!arr || !nrows))) return fail(SPDY_ERR_ARG, "bad argument");
-    if (!c->transpose || c->nranks == 1) return SPDY_OK;
+    if (!c->transpose || (c->nranks == 1 && !c->force)) return SPDY_OK;
     RC(spdy_sharded_step_workspace(c));
     const Shard s = shard_of(c);
     const Ranges rg = ranges_of(c);

@@ -290,6 +290,124 @@ def sharded_step_host(ex, st, rank, world, j1, j2, dt, eps, wil, sdrag, gather=a
     return new, fin
 
 
+def block_ranges(total, world, unit=16):
+    """The transposed form's horizontal ranges (csrc/spdy_api_shard.hip: block_ranges): the `total` points / coefficients in
+    blocks of `unit` (the column kernels' block size), rank r owns blocks [nblk r / world, nblk (r + 1) / world)."""
+    nblk = (total + unit - 1) // unit
+    out = []
+    for r in range(world):
+        b0, b1 = nblk * r // world, nblk * (r + 1) // world
+        out.append((min(total, b0 * unit), min(total, b1 * unit)))
+    return out
+
+
+def exchange_pieces(pieces):
+    """pieces[q] = what this rank sends to rank q (NumPy arrays); returns got[q] = what rank q sent here.  (An all-to-all spelled
+    with all_gather_object: the CPU tests' gloo backend has no all_to_all, and the volumes are a few hundred KB.)"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [None] * world
+    dist.all_gather_object(box, pieces)
+    return [box[q][rank] for q in range(world)]
+
+
+def sharded_step_host_transposed(ex, st, rank, world, j1, j2, dt, eps, wil, sdrag, ranges_valid=False, exchange=exchange_pieces):
+    """The data flow of the TRANSPOSED form of spdy_sharded_step_dev (include/spdy.h; csrc/spdy_api_shard.hip) on the host, with
+    `ex` as the executor of the single procedures, over any torch.distributed backend: levels <-> point ranges around the
+    grid-space column procedure, levels <-> coefficient ranges around the spectral side, four exchanges, nothing replicated.
+    st: this rank's prognostic arrays ({vor, div, t, tr: [2, kx, nx, mx]; ps: [2, nx, mx]; phis, tcorh, qcorh}); with
+    ranges_valid (every call but the first) they are current on (all levels x own coefficients) only and exchange 4 completes,
+    in place, what the inverse batch reads.  The column procedures are independent in the horizontal, so the executor runs them
+    on whole arrays that are zero outside the rank's range and only the range is kept.
+    Returns (state current on (all levels x own coefficients), final tendencies on the own coefficients + this rank's operands)."""
+    import numpy as np
+    kx, nx, mx = st["vor"].shape[1:]
+    lo, hi = shard_range(kx, rank, world)
+    nl, lv = hi - lo, j2 - 1
+    lev = [shard_range(kx, q, world) for q in range(world)]
+    st = {n: np.array(v) for n, v in st.items()}
+    flat = lambda a: a.reshape(a.shape[:-2] + (-1,))                            # [.., nx * mx] (or [.., il * ix]) view
+    cr = block_ranges(nx * mx, world)
+    c0, c1 = cr[rank]
+    # exchange 4 (coefficient ranges -> levels) of the previous step, where its result is first read
+    if ranges_valid and world > 1:
+        for n in ("vor", "div", "t", "tr"):
+            f = flat(st[n][lv])
+            got = exchange([f[lev[q][0]:lev[q][1], c0:c1].copy() for q in range(world)])
+            for q in range(world):
+                f[lo:hi, cr[q][0]:cr[q][1]] = got[q]
+        f = flat(st["ps"][lv])
+        got = exchange([f[c0:c1].copy() for _ in range(world)])
+        for q in range(world):
+            f[cr[q][0]:cr[q][1]] = got[q]
+    # inverse batch of the rank's levels -> its block [ug | vg | vorg | divg | tg | trg] (nl each); grad(ps) everywhere
+    blk = []
+    uv = [ex.uvspec(st["vor"][lv, k], st["div"][lv, k]) for k in range(lo, hi)]
+    blk += [ex.spec_to_grid(u, 2) for u, _ in uv] + [ex.spec_to_grid(v, 2) for _, v in uv]
+    for n in ("vor", "div", "t", "tr"):
+        blk += [ex.spec_to_grid(st[n][lv, k], 1) for k in range(lo, hi)]
+    dx, dy = ex.grad(st["ps"][lv])
+    px, py = ex.spec_to_grid(dx, 2), ex.spec_to_grid(dy, 2)
+    blk = np.stack(blk)
+    il, ix = blk.shape[1:]
+    pr = block_ranges(il * ix, world)
+    p0, p1 = pr[rank]
+    # exchange 1: levels -> point ranges
+    got = exchange([flat(blk)[:, pr[q][0]:pr[q][1]].copy() for q in range(world)])
+    cols = [np.zeros((kx, il * ix)) for _ in range(6)]                          # ug, vg, vorg, divg, tg, trg: all levels, own points
+    for q in range(world):
+        nq = lev[q][1] - lev[q][0]
+        for f in range(6):
+            cols[f][lev[q][0]:lev[q][1], p0:p1] = got[q][f * nq:(f + 1) * nq]
+    ug, vg, vorg, divg, tg, trg = (c.reshape(kx, il, ix) for c in cols)
+    U, V, PL = ex.grid_tendencies(ug, vg, tg, vorg, divg, trg, px, py)          # (every point is its own column: only [p0, p1) is kept)
+    # exchange 2 back: every rank's direct-batch operands (3 nl | 3 nl | 3 nl + 1 grids) come home
+    def operands_of(q):
+        own = [g * kx + k for g in range(3) for k in range(lev[q][0], lev[q][1])]
+        return np.concatenate([flat(U)[own, p0:p1], flat(V)[own, p0:p1], flat(PL)[own, p0:p1], flat(PL)[3 * kx:, p0:p1]])
+    got = exchange([operands_of(q) for q in range(world)])
+    ops = np.zeros((9 * nl + 1, il * ix))
+    for q in range(world):
+        ops[:, pr[q][0]:pr[q][1]] = got[q]
+    ops = ops.reshape(9 * nl + 1, il, ix)
+    Ul, Vl, PLl = ops[:3 * nl], ops[3 * nl:6 * nl], ops[6 * nl:]
+    # direct batch of the rank's levels incl. vds (+ the level-free ps tendency) -> [pvor | pdiv | pspec (3 nl each)] | psdt
+    vd = [ex.vdspec(Ul[i], Vl[i], 2) for i in range(3 * nl)]
+    blk = np.stack([x[0] for x in vd] + [x[1] for x in vd] + [ex.grid_to_spec(PLl[i]) for i in range(3 * nl + 1)])
+    # exchange 3: levels -> coefficient ranges
+    got = exchange([flat(blk)[:, cr[q][0]:cr[q][1]].copy() for q in range(world)])
+    pvor, pdiv, pspec = (np.zeros((3 * kx, nx * mx), complex) for _ in range(3))
+    psdt_in = np.zeros(nx * mx, complex)
+    for q in range(world):
+        nq = lev[q][1] - lev[q][0]
+        for g in range(3):
+            rows = slice(g * kx + lev[q][0], g * kx + lev[q][1])
+            pvor[rows, c0:c1] = got[q][g * nq:(g + 1) * nq]
+            pdiv[rows, c0:c1] = got[q][(3 + g) * nq:(4 + g) * nq]
+            pspec[rows, c0:c1] = got[q][(6 + g) * nq:(7 + g) * nq]
+        if q == 0:
+            psdt_in[c0:c1] = got[q][9 * nq]                                     # block 0's copy of the level-free tendency
+    sh3 = lambda a: a.reshape(a.shape[0], nx, mx)
+    pdiv, pspec = ex.tendency_combine(sh3(pdiv), np.concatenate([sh3(pspec), psdt_in.reshape(1, nx, mx)]))
+    vordt, divdt, tdt, trdt, psdt = sh3(pvor)[:kx], pdiv[:kx], pdiv[kx:2 * kx], pdiv[2 * kx:], pspec[3 * kx]
+    # the spectral side on all levels; every coefficient is independent: only [c0, c1) is kept
+    keep = np.zeros(nx * mx, bool)
+    keep[c0:c1] = True
+    keep = keep.reshape(nx, mx)
+    masked = lambda a: np.where(keep, a, 0.0)
+    s1 = {n: masked(st[n]) for n in ("vor", "div", "t", "tr", "ps")}
+    divdt, tdt, psdt, phi = ex.spectral_tendencies(s1["div"][0], s1["t"][0], s1["ps"][0], masked(st["phis"]), divdt, tdt, psdt)
+    divdt, tdt, psdt = ex.implicit_terms(divdt, tdt, psdt)
+    vordt, divdt, tdt, trdt = ex.hdiff_step(s1["vor"][0], s1["div"][0], s1["t"][0], s1["tr"][0], masked(st["tcorh"]), masked(st["qcorh"]), sdrag,
+                                            vordt, divdt, tdt, trdt)
+    new, fin = dict(st), {"phi": phi, "U": Ul, "V": Vl, "PL": PLl, "range": (c0, c1)}
+    upd, fin["psdt"] = ex.step_field(j1, dt, eps, wil, s1["ps"], psdt)
+    new["ps"] = np.where(keep, upd, st["ps"])
+    for n, d in (("vor", vordt), ("div", divdt), ("t", tdt), ("tr", trdt)):
+        upd, fin[n + "dt"] = ex.step_field(j1, dt, eps, wil, s1[n], d)
+        new[n] = np.where(keep, upd, st[n])
+    return new, fin
+
+
 def sharded_implicit_terms(sp, divdt_local, tdt_local, psdt, comm=None):
     """Level-sharded semi-implicit correction (implicit.f90:168-217 couples all levels of a coefficient): complete
     the level stacks with one all-gather, run implicit_terms on the full columns (independent per spectral

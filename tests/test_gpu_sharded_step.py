@@ -430,7 +430,57 @@ def test_sharded_step_rccl_graph_world1(tag, nccl_world1, oracle_factory, monkey
         g.close(); comm.close(); sp.close()
 
 
-def _rccl_rank(rank, world, port, tag, q):
+@pytest.mark.parametrize("tag", ["t30", "t63k16"])
+def test_sharded_step_transposed_rccl_world1_in_graph(tag, oracle_factory, monkeypatch):
+    """The transposed form over RCCL as ONE captured graph, at world size 1 with SPDY_COMM_FORCE=1: the rank's own piece of each
+    of the four exchanges really travels through grouped ncclSend / ncclRecv (and the state gather through ncclBroadcast), packed
+    and unpacked through the staging buffer by 2-D copies -- every node of the multi-rank route on a 1-GPU box.  Two replays
+    (the second starts with exchange 4 in the caller's arrays), then the gather, against the oracle and the unsharded device step."""
+    import torch
+    import speedy_f90_amd as s
+    kx = VARIANTS[tag][3]
+    o = oracle_factory(tag)
+    o.tail_init(DT)
+    sp0 = make_plan(tag)
+    st = state(sp0, 8000)
+    whole = unsharded_device_steps(sp0, st, 2)
+    sp0.close()
+    ref = st
+    for _ in range(2):
+        ref, out = oracle_dynamics_step(o, ref, 2, DT, ROB)
+    monkeypatch.setenv("SPDY_COMM_FORCE", "1")
+    monkeypatch.setenv("SPDY_SHARD_TRANSPOSE", "1")
+    sp = make_plan(tag)
+    sp.use_own_stream()
+    comm = s.sharding.LevelComm(sp)
+    comm.sharded_step_workspace()
+    d = comm.describe()
+    assert d["route"] == "rccl" and d["form"] == "transpose" and "rccl" in d["librccl"], d
+    D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
+    phi = torch.zeros((kx, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+    tend = torch.zeros((4 * kx + 1, sp.nx, sp.mx), dtype=torch.complex128, device="cuda")
+    torch.cuda.synchronize()
+    with sp.graph_capture() as g:
+        comm.sharded_step_(D["vor"], D["div"], D["t"], D["tr"], D["ps"], D["phis"], D["tcorh"], D["qcorh"], SDRAG, 2, 2, DT, ROB, WIL, phi, tend)
+    nodes = g.num_nodes()
+    for _ in range(2):
+        g.launch()
+    sp.synchronize()
+    comm.state_gather_(D["vor"], D["div"], D["t"], D["tr"], D["ps"])
+    comm.gather_ranges_(phi, tend)
+    sp.synchronize()
+    exact = tag.startswith("t30")
+    for n in PROGS:
+        got = D[n].cpu().numpy()
+        assert max(synth.relerr(got, ref[n]), wave_relerr(got, ref[n])) <= TOL, n
+        assert np.array_equal(got, whole[n]) if exact else synth.relerr(got, whole[n]) <= 1e-13, n
+    if exact:
+        assert np.array_equal(tend.cpu().numpy(), whole["tend"]) and np.array_equal(phi.cpu().numpy(), whole["phi"])
+    print("\n[transposed step over RCCL, world 1 forced, %s] %d graph nodes; librccl: %s" % (tag, nodes, d["librccl"]))
+    g.close(); comm.close(); sp.close()
+
+
+def _rccl_rank(rank, world, port, tag, q, transpose=False):
     import torch
     import torch.distributed as dist
     import speedy_f90_amd as s
@@ -448,6 +498,8 @@ def _rccl_rank(rank, world, port, tag, q):
         sp = make_plan(tag, device=rank)
         sp.use_own_stream()
         comm = s.sharding.LevelComm(sp)
+        if transpose:
+            comm.set_option("transpose", 1)
         comm.sharded_step_workspace()
         st = state(sp, 8000)
         D = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in st}
@@ -462,6 +514,9 @@ def _rccl_rank(rank, world, port, tag, q):
             g.launch()
             ref, out = oracle_dynamics_step(o, ref, 2, DT, ROB)
         sp.synchronize()
+        if transpose:
+            comm.state_gather_(D["vor"], D["div"], D["t"], D["tr"], D["ps"])
+            sp.synchronize()
         err = max(max(synth.relerr(D[n].cpu().numpy(), ref[n]), wave_relerr(D[n].cpu().numpy(), ref[n])) for n in PROGS)
         g.close(); comm.close(); sp.close()
         q.put((rank, err))
@@ -469,12 +524,14 @@ def _rccl_rank(rank, world, port, tag, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transpose", [False, True])
 @pytest.mark.parametrize("world,tag", [(2, "t30"), (3, "t30"), (2, "t63k16"), (4, "t30"), (8, "t30"), (4, "t63k16"), (8, "t63k16")])
-def test_sharded_step_rccl_ranks(world, tag):
+def test_sharded_step_rccl_ranks(world, tag, transpose):
     """BASELINE config 3 on real RCCL ranks (one process per GPU): every rank captures the complete sharded step -- its two
     all-gathers included -- into a graph, replays it twice from NaN-poisoned exchange stacks and must hold the oracle's
     prognostics.  world 3 with 8 levels: ragged blocks -> grouped ncclBroadcast; world 8 at T30 L8 is config 3's own rank
-    count (one level per rank), world 8 at T63 L16 two levels per rank.  Skipped on boxes with fewer GPUs."""
+    count (one level per rank), world 8 at T63 L16 two levels per rank.  transpose: the transposed form (four grouped
+    ncclSend / ncclRecv exchanges, then the state gather).  Skipped on boxes with fewer GPUs."""
     import torch
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
@@ -482,7 +539,7 @@ def test_sharded_step_rccl_ranks(world, tag):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, tag, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, tag, q, transpose)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:

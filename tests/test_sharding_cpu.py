@@ -123,6 +123,60 @@ def test_multi_rank_sharded_step(world, kx, tmp_path):
         assert np.array_equal(z["PL"], np.concatenate([out["PL"][own], out["PL"][3 * kx:]]))
 
 
+def _transposed_worker(rank, world, port, kx, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import speedy_f90_amd as s
+    from oracle.pyoracle import Oracle
+    from dynstep import ROB, SDRAG, WIL, state
+    o = Oracle(30, 96, 24, kx)
+    o.tail_init(2400.0)
+    st = state(o, 8000)
+    for step in range(2):                     # the second step starts with exchange 4 in the rank's own arrays
+        st, fin = s.sharding.sharded_step_host_transposed(o, st, rank, world, 2, 2, 2400.0, ROB, WIL, SDRAG, ranges_valid=step > 0)
+    np.savez(os.path.join(outdir, "tstep_%d.npz" % rank), c0=fin["range"][0], c1=fin["range"][1],
+             **{n: st[n] for n in ("vor", "div", "t", "tr", "ps")},
+             **{n: fin[n] for n in ("vordt", "divdt", "tdt", "trdt", "psdt", "phi", "U", "V", "PL")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kx", [(2, 8), (3, 8), (8, 8)])
+def test_multi_rank_transposed_step(world, kx, tmp_path):
+    """The TRANSPOSED form of the level-sharded step (sharding.sharded_step_host_transposed: the data flow of spdy_sharded_step_dev
+    with spdy_comm_set_option "transpose", the oracle as executor) over gloo: levels <-> point ranges around
+    get_grid_point_tendencies (tendencies.f90:109-197), levels <-> coefficient ranges around get_spectral_tendencies /
+    implicit_terms / diffusion / leapfrog (tendencies.f90:242-293, implicit.f90:168-217, time_stepping.f90:56-167).  After two
+    chained steps every rank must hold, on ITS coefficients, the unsharded oracle step's prognostics and tendencies bit for bit,
+    the ranges must tile the spectrum, and its levels' direct-batch operands must have come home complete."""
+    port = _free_port()
+    mp.spawn(_transposed_worker, args=(world, port, kx, str(tmp_path)), nprocs=world, join=True)
+    import speedy_f90_amd as s
+    from oracle.pyoracle import Oracle
+    from dynstep import ROB, SDRAG, WIL, oracle_dynamics_step, state
+    o = Oracle(30, 96, 24, kx)
+    o.tail_init(2400.0)
+    ref = state(o, 8000)
+    for step in range(2):
+        ref, out = oracle_dynamics_step(o, ref, 2, 2400.0, ROB)
+    flat = lambda a: a.reshape(a.shape[:-2] + (-1,))
+    covered = 0
+    for r in range(world):
+        z = np.load(tmp_path / ("tstep_%d.npz" % r))
+        c0, c1 = int(z["c0"]), int(z["c1"])
+        assert (c0, c1) == s.sharding.block_ranges(32 * 31, world)[r]
+        covered += c1 - c0
+        for n in ("vor", "div", "t", "tr", "ps"):
+            assert np.array_equal(flat(z[n])[..., c0:c1], flat(ref[n])[..., c0:c1]), (r, n)
+        for n in ("vordt", "divdt", "tdt", "trdt", "psdt", "phi"):
+            assert np.array_equal(flat(z[n])[..., c0:c1], flat(out[n])[..., c0:c1]), (r, n)
+        lo, hi = s.sharding.shard_range(kx, r, world)
+        own = [g * kx + k for g in range(3) for k in range(lo, hi)]
+        assert np.array_equal(z["U"], out["U"][own]) and np.array_equal(z["V"], out["V"][own])
+        assert np.array_equal(z["PL"], np.concatenate([out["PL"][own], out["PL"][3 * kx:]]))
+    assert covered == 32 * 31
+
+
 def test_level_block_layout():
     """The level-block stacks of the sharded step (csrc/spdy_kernels.hpp: LevelShard; mirrored by sharding.block_slab): every
     (field, level) -- and every rank's level-free extra slab -- has exactly one slab, a rank's slabs are contiguous, and the
