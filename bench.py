@@ -895,7 +895,8 @@ def main():
                 per_field = tj.get(args.res, {}).get(dom)
                 traffic = per_field * nb if per_field else None
                 if traffic:
-                    traffic_source = "profiles/pmc_traffic.json (%s): rocprofv3 PMC passes of an earlier run of this command, bytes per field x %d fields; not measured in this run" % (tj.get("source", "committed"), nb)
+                    src = tj.get("sources", {}).get("%s/%s" % (args.res, dom)) or tj.get("source", "committed")      # (per entry: the file may carry passes of several rounds)
+                    traffic_source = "profiles/pmc_traffic.json (%s): rocprofv3 PMC passes of an earlier run of this command, bytes per field x %d fields; not measured in this run" % (src, nb)
                 # FP64 matrix-pipe utilisation of the dominant kernel: its matrix instructions are a fixed count per field
                 # (SQ_VALU_MFMA_BUSY_CYCLES of the committed counter pass: 16 cycles per v_mfma_f64_4x4x4_4b, summed over the
                 # SIMDs) -- divided by THIS run's launch duration x shader clock x SIMDs

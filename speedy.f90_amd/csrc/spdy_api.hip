@@ -515,6 +515,16 @@ bool use_fused63(const spdy_plan *p, int nb) { (void)nb; return p->tab.trunc == 
 // The composite entry points (uvspec/grad -> grid, vdspec, the mixed batches) are one fused launch against two to four
 // four-kernel sequences: the fused kernels win there at any size.
 bool use_fused63_composite(const spdy_plan *p) { return p->tab.trunc == 63 && p->fused_mode != 0; }
+// T30: a step's whole direct batch is ONE mixed-tile launch (MODE 3) -- what a latency-bound, model-sized batch wants.  At
+// throughput sizes (the launch streams: >= 16 MB of grids) the launch count does not matter and the mixed-mode direct kernel --
+// out of registers, it reads its vds factors where it uses them -- runs at 0.48 of the HBM roofline where the pair kernel
+// (0.58) and the plain kernel (0.69) on their own average 0.54 (round 6, same box: 0.485 -> 0.541): such batches go out as the
+// two launches.  The INVERSE mixed launch keeps its one launch at every size (0.58 against 0.56 split, measured the same day).
+// A field's bits do not depend on the launch it travels in (tests/test_gpu_determinism.py, test_gpu_fused_ops.py).
+bool one_mixed_launch(const spdy_plan *p, long fields)
+{
+    return !spdy::streams(fields * (long)grid_elems(p) * 8);
+}
 
 template <class F> int timed(spdy_plan *p, int kind, F &&launch)
 {
@@ -1287,7 +1297,7 @@ int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const doub
     RC(check_batch(p, npairs));
     RC(check_batch(p, nplain));
     if ((npairs && (!ug || !vg || !vorm || !divm)) || (nplain && (!grid || !spec))) return fail(SPDY_ERR_ARG, "null device pointer");
-    if (use_fused(p, npairs) && npairs > 0 && nplain > 0) {
+    if (use_fused(p, npairs) && npairs > 0 && nplain > 0 && one_mixed_launch(p, 2L * npairs + nplain)) {
         const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
         return timed(p, SPDY_K_G2S_FUSED, [&] {
             return spdy::launch_g2s_fused(p->dev, npairs, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm, nplain, grid, spec);

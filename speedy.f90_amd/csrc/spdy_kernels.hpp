@@ -203,6 +203,9 @@ struct GridTend {
     double *tr_out;
 };
 hipError_t launch_grid_tendencies(const DevPlan &p, const GridTend &g, hipStream_t s);
+// Whether a fused launch with this many grid-side bytes streams them (non-temporal loads / stores; >= 16 MB): the size from which
+// a launch is throughput-bound rather than latency-bound
+bool streams(long grid_bytes);
 // Write-through policy of a model-sized launch (the step's kernels): outputs of at least p.lo.wt_min_mb MB (default 6; 0 = never)
 // leave the L2s as they are produced instead of waiting, dirty, for the end-of-kernel release.
 bool write_through_policy(const DevPlan &p, long output_bytes);
