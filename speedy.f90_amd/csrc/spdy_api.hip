@@ -1122,6 +1122,15 @@ int spdy_vdspec_dev(spdy_plan *p, int nb, const double *ug, const double *vg, do
                                       !in_host_stage(p, ug)));
         return SPDY_OK;
     }
+    if (use_fused63_composite(p) && spdy::g2s_t63_staged(p->dev, p->num_cu, nb)) {
+        // T63, model-sized (row f1, round 6): the pairs (ug[i], vg[i]) as ONE segment of the staged form -- rows launch, then the
+        // contraction applies vds to the pair's spectra in registers: no vds launch, no raw spectra in HBM
+        spdy::T63Batch b{};
+        b.nseg = 1;
+        b.seg[0] = spdy::T63Seg{ug, vorm, sc, nullptr, nb, 1, 0, spdy::T63_OP_VDS};
+        b.vds_src2 = vg; b.vds_dst2 = divm;
+        return timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
+    }
     if (use_fused63_composite(p)) {             // both scaled transforms in ONE fused launch (two segments) + vds
         RC(ensure_four(p));
         spdy::T63Batch b{};
@@ -1302,6 +1311,16 @@ int spdy_direct_batch_dev(spdy_plan *p, int npairs, const double *ug, const doub
         return timed(p, SPDY_K_G2S_FUSED, [&] {
             return spdy::launch_g2s_fused(p->dev, npairs, ug, sc, vorm, p->num_cu * p->wg_per_cu, p->stream, vg, divm, nplain, grid, spec);
         });
+    }
+    if (npairs > 0 && nplain > 0 && use_fused63_composite(p) && spdy::g2s_t63_staged(p->dev, p->num_cu, npairs + (nplain + 1) / 2)) {
+        // T63, model-sized: the (u, v) pairs (vds in the contraction) and the plain grids as two segments of the staged form
+        const double *sc = kcos == 2 ? p->dev.cosgr : p->dev.cosgr2;
+        spdy::T63Batch b{};
+        b.nseg = 2;
+        b.seg[0] = spdy::T63Seg{ug, vorm, sc, nullptr, npairs, 1, 0, spdy::T63_OP_VDS};
+        b.vds_src2 = vg; b.vds_dst2 = divm;
+        b.seg[1] = spdy::T63Seg{grid, spec, nullptr, nullptr, nplain, 1, 0, 0};
+        return timed(p, SPDY_K_G2S_FUSED, [&] { return spdy::launch_g2s_fused_t63_batch(p->dev, b, p->num_cu, p->stream); });
     }
     if (npairs > 0 && nplain > 0 && use_fused63_composite(p)) {
         // T63: the scaled u, v grids and the plain grids as three segments of ONE fused launch, then vds

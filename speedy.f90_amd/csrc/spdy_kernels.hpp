@@ -120,22 +120,30 @@ struct T63Seg {
     const int *kcos;       // inverse: per-field kcos (device), or nullptr for kcos_all
     int nb, kcos_all, pair0;
     int op;                // inverse: 0 = src holds the spectra; T63_OP_* = they are derived from src / (const double *)scale on load
+                           // direct: T63_OP_VDS = vdspec pairs -- pair i of the segment is (src[i], T63Batch::vds_src2[i]) = (u, v) grids,
+                           // nb pairs; the contraction applies vds (spectral.f90:146-171) to the pair's spectra in registers:
+                           // vorticity -> dst[i], divergence -> T63Batch::vds_dst2[i]
 };
 // spectral operators folded into the inverse kernel's operand load (spectral.f90:124-196): the segment's spectra are
 //   U / V of uvspec(vor = src, div = scale)  or  d/dlambda / d/dmu of grad(psi = src)
-enum { T63_OP_NONE = 0, T63_OP_U = 1, T63_OP_V = 2, T63_OP_GX = 3, T63_OP_GY = 4 };
+enum { T63_OP_NONE = 0, T63_OP_U = 1, T63_OP_V = 2, T63_OP_GX = 3, T63_OP_GY = 4, T63_OP_VDS = 5 };
 struct T63Batch {
     int nseg, npairs;
     int by_chunk, wt;      // inverse, small batches: work items are (pair, chunk) instead of whole pairs; model-sized launches with
                            // several MB of output: stores written through (both set by the launcher)
     int nop_items, ipw;    // by-chunk walk (set by the launcher): items of the derived segments (one per workgroup), items per
                            // workgroup behind them
+    const double *vds_src2; // direct launches: the second arrays of the (one) T63_OP_VDS segment -- in the header, not in the
+    double *vds_dst2;       // segment, whose size decides whether the compiler indexes the by-value argument or copies it to scratch
     T63Seg seg[T63_MAX_SEG];
 };
 hipError_t launch_s2g_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
 // whether an inverse launch of `pairs` field pairs may carry `op_pairs` derived ones (model-sized launches: the by-chunk form)
 bool s2g_t63_derives(int max_wg, int pairs, int op_pairs);
 hipError_t launch_g2s_fused_t63_batch(const DevPlan &p, T63Batch b, int max_wg, hipStream_t s);
+// whether a direct launch of `pairs` field pairs takes the STAGED form (rows launch + contraction launch: model-sized batches) --
+// the form that can apply vds to T63_OP_VDS segments (callers otherwise run vds as a kernel behind the launch)
+bool g2s_t63_staged(const DevPlan &p, int max_wg, int pairs);
 hipError_t launch_g2s_fused_t63(const DevPlan &p, int nb, const double *grid, const double *gscale, double *spec, int max_wg, hipStream_t s);
 
 enum SpecOp { OP_LAPLACIAN = 0, OP_INV_LAPLACIAN = 1, OP_TRUNCT = 2 };

@@ -151,8 +151,8 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
     """Small T63 direct batches (at most half as many pairs as CUs) run STAGED -- the row FFTs as a launch of their own over
     (pair, chunk, field) items, then the fused kernel's Legendre waves fed by movers (csrc/spdy_fused_t63.inc) -- instead of one
     fused launch whose eight steps are each as long as one FFT wave's phase.  Same code for every row, same accumulation order:
-    the staged form, the fused split form (option t63_stage = 0) and a large batch's whole-pair walk must agree BIT FOR BIT, for plain
-    fields, for the scaled pairs of vdspec and for a model step's three-segment direct batch."""
+    the staged form, the fused split form (option t63_stage = 0) and a large batch's whole-pair walk must agree BIT FOR BIT for plain
+    fields (alone and as a segment of a model step's direct batch); the vdspec pairs agree to rounding (vds in registers vs as a kernel)."""
     import torch
     import speedy_f90_amd as s
     sp = s.Spectral("t63", kx=8, max_batch=600, device=0)
@@ -175,7 +175,14 @@ def test_t63_small_direct_forms_agree(nb, monkeypatch):
     sp.set_option("t63_stage", 1)
     for k in a:
         assert not torch.isnan(torch.view_as_real(a[k])).any(), k
-        assert torch.equal(a[k], b[k]), (nb, k)
+        if k in ("plain", "mpl"):
+            assert torch.equal(a[k], b[k]), (nb, k)
+        else:
+            # the vdspec pairs: the TRANSFORMS are the same bits in both forms, but since round 6 the staged form applies vds to the
+            # pair's spectra in registers (csrc/spdy_fused_t63.inc: t63_dir_writeout_vds) where the fused form runs vds_kernel
+            # behind the launch -- the same expressions, contracted differently by the compiler: equal to rounding
+            x, y = torch.view_as_real(a[k]), torch.view_as_real(b[k])
+            assert float((x - y).abs().max()) <= 1e-13 * float(y.abs().max()), (nb, k)
     # ... and inside a batch large enough for the whole-pair walk of the throughput form
     big = c128(600)
     sp.grid_to_spec_dev(G, big)
