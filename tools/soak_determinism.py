@@ -30,3 +30,35 @@ for res, nb in (("t63", 1536), ("t63", 146), ("t63", 72), ("t63", 9), ("t30", 61
     print("%s nb=%-5d %d round trips: %d launches with different spectra, %d with different grids  (%.1f s)"
           % (res, nb, n, int(bad_s), int(bad_g), time.time() - t0), flush=True)
     sp.close()
+
+# round 6: the operators folded into the T63 model-sized launches -- uvspec / grad derived by all eight waves and staged through LDS
+# (by-chunk inverse kernel), vds in the staged contraction's registers: every launch against the first
+import synth
+sp = s.Spectral("t63", kx=16, max_batch=80, device=0)
+sp.use_torch_stream()
+S = torch.from_numpy(synth.spectra(6 * 16 + 1, 63, first=3, full_rows=True)).cuda()
+f64 = lambda k: torch.zeros(k, sp.il, sp.ix, dtype=torch.float64, device="cuda")
+c128 = lambda k: torch.zeros(k, sp.nx, sp.mx, dtype=torch.complex128, device="cuda")
+ug, vg, pg, gx, gy, vo, dv = f64(16), f64(16), f64(64), f64(1), f64(1), c128(16), c128(16)
+
+
+def folded():
+    sp.inverse_batch_grad_dev(S[:16], S[16:32], ug, vg, S[32:96], pg, S[96:], gx, gy, kcos_pairs=2, kcos=1, kcos_grad=2)
+    sp.vdspec_dev(ug, vg, vo, dv, 2)
+    return [t.clone() for t in (ug, vg, pg, gx, gy, vo, dv)]
+
+
+first = folded()
+bad = torch.zeros((), dtype=torch.int64, device="cuda")
+t0 = time.time()
+for i in range(n):
+    for t in (ug, vg, pg, gx, gy):
+        t.zero_()
+    now = folded()
+    for a, b in zip(now, first):
+        bad += (torch.view_as_real(a) != torch.view_as_real(b)).any() if a.is_complex() else (a != b).any()
+torch.cuda.synchronize()
+print("t63 L16 step-shaped inverse batch (uvspec | grad derived on load) + vdspec (vds in the contraction), %d repeats: %d arrays that differed  (%.1f s)"
+      % (n, int(bad.item()), time.time() - t0))
+sp.close()
+
