@@ -636,27 +636,34 @@ int spdy_sharded_step_workspace(spdy_comm *c)
     spdy_plan *p = c->plan;
     NEED_DEVICE(p);
     RC(need_sharded(c));
-    if (c->T) return SPDY_OK;
+    if (c->T && (!c->transpose || c->Tb)) return SPDY_OK;
     NOT_CAPTURING(p, "allocating the sharded step's workspace (call spdy_sharded_step_workspace before the capture)");
     const Shard s = shard_of(c);
     const int kx = p->tab.kx;
     const size_t P = (size_t)3 * s.nl;
-    const Ranges rg = ranges_of(c);
-    const size_t npts = rg.gl[c->rank], ned = rg.sl[c->rank];
-    // (U | V | PL are ONE allocation: the rank's block of the F = 9, X = 1 operand stack of the transposed form)
-    struct { double **dst; size_t n; } want[10] = {
-        {&c->G, (size_t)6 * kx * s.gs}, {&c->px, s.gs}, {&c->py, s.gs}, {&c->U, (3 * P + 1) * s.gs},
-        {&c->tend, (size_t)(4 * kx + 1) * s.ss}, {&c->T, (size_t)(9 * kx + c->nranks) * s.ss},
-        {&c->Gb, (size_t)6 * kx * npts}, {&c->Ob, (size_t)(9 * kx + c->nranks) * npts}, {&c->Tb, (size_t)(9 * kx + c->nranks) * ned},
-        {&c->stage, std::max((3 * P + 1) * s.gs, (size_t)(4 * kx + 2) * s.ss) + (size_t)(2 * kx + 2) * s.ss + (size_t)(9 * kx + c->nranks) * std::max(npts, ned)}};
-    for (auto &w : want) {
+    auto alloc0 = [&](double **dst, size_t n) -> int {         // zero-filled plan-owned device memory
         void *ptr;
-        RC(dev_alloc(p, std::max<size_t>(w.n, 2) * sizeof(double), &ptr));
-        HIP_TRY(hipMemsetAsync(ptr, 0, std::max<size_t>(w.n, 2) * sizeof(double), p->stream));
-        *w.dst = static_cast<double *>(ptr);
+        RC(dev_alloc(p, std::max<size_t>(n, 2) * sizeof(double), &ptr));
+        HIP_TRY(hipMemsetAsync(ptr, 0, std::max<size_t>(n, 2) * sizeof(double), p->stream));
+        *dst = static_cast<double *>(ptr);
+        return SPDY_OK;
+    };
+    if (!c->T) {
+        // (U | V | PL are ONE allocation: the rank's block of the F = 9, X = 1 operand stack of the transposed form)
+        RC(alloc0(&c->G, (size_t)6 * kx * s.gs)); RC(alloc0(&c->px, s.gs)); RC(alloc0(&c->py, s.gs)); RC(alloc0(&c->U, (3 * P + 1) * s.gs));
+        RC(alloc0(&c->tend, (size_t)(4 * kx + 1) * s.ss)); RC(alloc0(&c->T, (size_t)(9 * kx + c->nranks) * s.ss));
+        c->V = c->U + P * s.gs;
+        c->PL = c->V + P * s.gs;
     }
-    c->V = c->U + P * s.gs;
-    c->PL = c->V + P * s.gs;
+    if (c->transpose && !c->Tb) {
+        // the transposed form's range stacks (all levels of the own points / coefficients) and the RCCL route's staging buffer
+        const Ranges rg = ranges_of(c);
+        const size_t npts = rg.gl[c->rank], ned = rg.sl[c->rank];
+        RC(alloc0(&c->Gb, (size_t)6 * kx * npts)); RC(alloc0(&c->Ob, (size_t)(9 * kx + c->nranks) * npts));
+        RC(alloc0(&c->stage, std::max((3 * P + 1) * s.gs, (size_t)(4 * kx + 2) * s.ss) + (size_t)(2 * kx + 2) * s.ss
+                                 + (size_t)(9 * kx + c->nranks) * std::max(npts, ned)));
+        RC(alloc0(&c->Tb, (size_t)(9 * kx + c->nranks) * ned));
+    }
     return SPDY_OK;
 }
 

@@ -240,7 +240,8 @@ def test_sharded_step_transposed_in_process_ranks(tag, world, oracle_factory, mo
     assert worst <= TOL, (tag, world, worst)
 
 
-def test_sharded_step_in_process_ranks_on_several_devices(oracle_factory, monkeypatch):
+@pytest.mark.parametrize("transpose", [False, True])
+def test_sharded_step_in_process_ranks_on_several_devices(transpose, oracle_factory, monkeypatch):
     """The in-process group with one DEVICE per rank -- what a single-process host driving several GPUs runs: the exchanges are
     peer copies (hipMemcpyPeerAsync) between the ranks' streams.  Skipped on 1-GPU boxes."""
     import torch
@@ -257,7 +258,7 @@ def test_sharded_step_in_process_ranks_on_several_devices(oracle_factory, monkey
     whole = unsharded_device_steps(sp0, st, nsteps)
     group = s.sharding.LocalGroup(sp0.lib, world)
     results, errors = {}, {}
-    threads = [threading.Thread(target=_rank_thread, args=(r, group, tag, st, nsteps, results, errors, r)) for r in range(world)]
+    threads = [threading.Thread(target=_rank_thread, args=(r, group, tag, st, nsteps, results, errors, r, transpose)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
