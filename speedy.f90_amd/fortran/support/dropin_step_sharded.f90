@@ -85,6 +85,16 @@ contains
             call spdy_check(spdy_sharded_step_dev(comm, d_vor, d_div, d_t, d_tr, d_ps, d_phis, d_tcorh, d_qcorh, real(sdrag, c_double), &
                 & 2_c_int, 2_c_int, real(dt, c_double), real(rob, c_double), real(wil, c_double), d_phi, d_tend), 'sharded_step_dev')
         end do
+        ! the transposed form ($SPDY_SHARD_TRANSPOSE=1 when the communicator is created) leaves every array current on the rank's own
+        ! coefficients only: make them whole before they are read back (no-ops in the all-gather form)
+        call spdy_check(spdy_sharded_state_gather_dev(comm, d_vor, d_div, d_t, d_tr, d_ps), 'sharded_state_gather_dev')
+        block
+            type(c_ptr) :: arrs(2)
+            integer(c_int) :: rows(2)
+            arrs = (/ d_phi, d_tend /)
+            rows = (/ int(kx, c_int), int(4*kx + 1, c_int) /)
+            call spdy_check(spdy_sharded_gather_ranges_dev(comm, 2_c_int, arrs, rows), 'sharded_gather_ranges_dev')
+        end block
         call spdy_check(spdy_plan_synchronize(plan), 'plan_synchronize')
         o = 0
         call fetch(plan, rank, o, d_vor, 2*kx); call fetch(plan, rank, o, d_div, 2*kx); call fetch(plan, rank, o, d_t, 2*kx)

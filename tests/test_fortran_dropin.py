@@ -291,6 +291,19 @@ def test_sharded_step_from_one_fortran_process(tag, tmp_path, oracle_factory):
         assert r.stdout.count("transforms levels") == world, r.stdout
         raws[world] = np.fromfile(fout, np.float64).view(np.complex128)
         assert np.array_equal(raws[world].view(np.int64), raws[1].view(np.int64)), world
+        # ... and the TRANSPOSED form of the same step (levels <-> point / coefficient ranges; include/spdy.h) from the same Fortran
+        # host: the environment selects it when the communicators are created, the driver gathers the state before reading it back.
+        # Same bytes as the all-gather form at T30; at T63 to rounding (there the all-gather form applies vds inside the spectral
+        # step, the transposed form before its exchange).
+        ft = tmp_path / ("out%dt.bin" % world)
+        r = subprocess.run([exe, str(fin), str(ft), str(nleap), str(world)], capture_output=True, text=True, timeout=300,
+                           env=dict(env, SPDY_SHARD_TRANSPOSE="1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        tr_ = np.fromfile(ft, np.float64).view(np.complex128)
+        if tag == "t30":
+            assert np.array_equal(tr_.view(np.int64), raws[1].view(np.int64)), ("transposed", world)
+        else:
+            assert tr_.shape == raws[1].shape and synth.relerr(tr_, raws[1]) <= 1e-13, ("transposed", world, synth.relerr(tr_, raws[1]))
     delt = float(np.float32(86400.0) / np.float32(36))               # params.f90:31
     o.tail_init(2 * delt)
     ref = st
