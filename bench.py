@@ -528,6 +528,62 @@ def fortran_step_loop():
     return res
 
 
+PMC_KERNELS = {   # kernel-name prefix as rocprofv3 prints it -> (resolution, kind)
+    "spdy::s2g_fused_t30_kernel<0, true, false>": ("t30", "s2g_fused"), "spdy::g2s_fused_t30_kernel<0, true, 1>": ("t30", "g2s_fused"),
+    "spdy::s2g_fused_t63_kernel<true, false, false>": ("t63", "s2g_fused"), "spdy::g2s_fused_t63_kernel<0, true, false>": ("t63", "g2s_fused"),
+}
+
+
+def live_pmc_traffic(res, nb, fused, timeout_s=150.0):
+    """HBM bytes per launch of the two throughput kernels MEASURED in this run: two short rocprofv3 counter passes (FETCH_SIZE, then
+    WRITE_SIZE -- separate passes, kernel-trace only, as MI355X_MICROARCH.md prescribes) of this very command (--steps 4, no side
+    measurements) in a child process; bytes = (2 x FETCH_SIZE [the counter counts 64-byte halves of the 128-byte lines HBM delivers on
+    gfx950] + WRITE_SIZE) KB x 1024, median over the kernel's dispatches.  Returns ({kind: bytes per launch}, note) or (None, why)."""
+    import shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="spdy_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    med, t0 = {}, time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--res", res,
+                   "--batch", str(nb), "--fused", str(fused), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-graph", "--no-pmc"]
+            left = timeout_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None, "rocprofv3 passes ran out of time"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            vals = {}
+            c = sqlite3.connect(dbs[0])
+            for name, cn, v in c.execute("select kernel_name,counter_name,value from counters_collection"):
+                name = name.replace("void ", "").split("(")[0]
+                for k, (rr, kind) in PMC_KERNELS.items():
+                    if rr == res and name.startswith(k) and cn == counter:
+                        vals.setdefault(kind, []).append(v)
+            c.close()
+            for kind, v in vals.items():
+                v.sort()
+                med.setdefault(kind, {})[counter] = (v[len(v) // 2], len(v))
+    except Exception as e:
+        return None, "rocprofv3 passes failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for kind, m in med.items():
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            out[kind] = (2.0 * m["FETCH_SIZE"][0] + m["WRITE_SIZE"][0]) * 1024.0
+    if not out:
+        return None, "no counter rows for the fused kernels"
+    n = min(m["FETCH_SIZE"][1] for m in med.values() if "FETCH_SIZE" in m)
+    return out, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes of this command with --steps 4, "
+                 "%d dispatches per kernel, median), (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch; %.0f s" % (n, time.perf_counter() - t0))
+
+
 def flatten_for_driver(res, this_res):
     """The driver's record of this line keeps the top-level scalars and the SCALAR members of `roofline`, `cpu_baseline` and
     `config` (BENCH_rNN.json `parsed`; everything nested deeper, and `extras` as a whole, survives only as text in `tail`).
@@ -777,6 +833,8 @@ def main():
     ap.add_argument("--multi-timeout", type=float, default=90.0, help="seconds before the `multi_gpu` measurements are abandoned")
     ap.add_argument("--dry-launch", action="store_true", help="start the ranks, print each rank's launcher environment as JSON, exit (no GPU needed)")
     ap.add_argument("--no-extras", action="store_true", help="skip the model-shaped / operator-fused / T63 side measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure `roofline.traffic` with rocprofv3 counter passes of a child run (N = 1 only; "
+                                                          "falls back to the committed per-field figures of profiles/pmc_traffic.json)")
     ap.add_argument("--fused", type=int, default=-1, help="1 fused single-pass kernels, 0 four-kernel path, -1 auto")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -910,6 +968,17 @@ def main():
                                    "%.2f GHz x %d SIMDs)" % (tj.get("source", "committed"), nb, clock_hz * 1e-9, simds))
             except Exception:
                 traffic = None
+        # ... unless this run can measure it itself (N = 1; rank 0 is the only rank): a child run of this command under rocprofv3
+        if world == 1 and not args.no_pmc:
+            live, note = live_pmc_traffic(args.res, nb, args.fused)
+            if live and dom in live:
+                traffic, traffic_source = live[dom], note
+                traffic_all = live
+            else:
+                traffic_all = None
+                traffic_source = (traffic_source or "") + " [live rocprofv3 passes unavailable: %s]" % note
+        else:
+            traffic_all = None
         res = {
             "metric": "spectral transforms/sec (grid<->spec round-trip) at %s L8" % args.res.upper(),
             "value": value, "unit": "round trips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -926,6 +995,7 @@ def main():
             "path_hbm_frac": value / world * ab["round_trip"] / (HBM_PEAK_GBS * 1e9),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": (traffic / (ab[dom] * nb)) if traffic else None, "traffic_all_kernels": traffic_all,
                          "launch_ms": dom_ms, "bytes_per_launch": ab[dom] * nb,
                          "mfma_util": mfma_util, "mfma_util_source": mfma_source,
                          "all_kernels_ms": kinds,

@@ -6,9 +6,9 @@ tag=${1:-prof}; shift
 out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 # (--no-extras: only the metric's own launches, so that a kernel's average duration and counters are those of ONE batch size)
-cmd="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras $*"
+cmd="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-pmc $*"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python $OLDPWD/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras "$@" > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python $OLDPWD/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras --no-pmc "$@" > $out/kt.log 2>&1
 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $out/fetch -o fetch -- $cmd > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $out/write -o write -- $cmd > $out/write.log 2>&1
 rocprofv3 --kernel-trace --stats --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES -d $out/sq -o sq -- $cmd > $out/sq.log 2>&1
