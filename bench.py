@@ -547,19 +547,32 @@ def live_pmc_traffic(res, nb, fused, timeout_s=150.0):
     env = dict(os.environ, TMPDIR="/tmp")
     med, t0 = {}, time.perf_counter()
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--res", res,
-                   "--batch", str(nb), "--fused", str(fused), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-graph", "--no-pmc"]
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", None):
+            out = os.path.join(tmp, counter or "trace")
+            # (the third pass: kernel trace only, the K steps replayed as ONE graph like the timed region -- the kernels' average
+            # durations in the launch mode `value` is measured in)
+            cmd = [exe, "--kernel-trace"] + (["--pmc", counter] if counter else ["--stats"]) + ["-d", out, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--res", res, "--batch", str(nb), "--fused", str(fused), "--steps", "4" if counter else "20", "--warmup", "2",
+                   "--no-cpu-baseline", "--no-extras", "--no-pmc"] + (["--no-graph"] if counter else [])
             left = timeout_s - (time.perf_counter() - t0)
             if left < 20:
                 return None, "rocprofv3 passes ran out of time"
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
             if r.returncode != 0 or not dbs:
+                if counter is None:
+                    break                                   # (the trace pass is a bonus: the counters stand without it)
                 return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
             vals = {}
             c = sqlite3.connect(dbs[0])
+            if counter is None:
+                for name, calls, avg in c.execute("select name,total_calls,average from top_kernels"):
+                    name = name.replace("void ", "").split("(")[0]
+                    for k, (rr, kind) in PMC_KERNELS.items():
+                        if rr == res and name.startswith(k):
+                            med.setdefault(kind, {})["avg_us_in_graph"] = (float(avg), int(calls))
+                c.close()
+                continue
             for name, cn, v in c.execute("select kernel_name,counter_name,value from counters_collection"):
                 name = name.replace("void ", "").split("(")[0]
                 for k, (rr, kind) in PMC_KERNELS.items():
@@ -580,6 +593,8 @@ def live_pmc_traffic(res, nb, fused, timeout_s=150.0):
     if not out:
         return None, "no counter rows for the fused kernels"
     n = min(m["FETCH_SIZE"][1] for m in med.values() if "FETCH_SIZE" in m)
+    out["_avg_us_in_graph"] = {kind: m["avg_us_in_graph"][0] for kind, m in med.items() if "avg_us_in_graph" in m}
+    out["_calls_in_graph"] = {kind: m["avg_us_in_graph"][1] for kind, m in med.items() if "avg_us_in_graph" in m}
     return out, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes of this command with --steps 4, "
                  "%d dispatches per kernel, median), (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch; %.0f s" % (n, time.perf_counter() - t0))
 
@@ -946,6 +961,7 @@ def main():
         # figure of the committed counter passes (profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE per launch / fields,
         # source file named there) times this run's batch; `traffic_source` says so
         traffic, traffic_source, mfma_util, mfma_source = None, None, None, None
+        rocprof_us, rocprof_calls = {}, {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -973,7 +989,8 @@ def main():
             live, note = live_pmc_traffic(args.res, nb, args.fused)
             if live and dom in live:
                 traffic, traffic_source = live[dom], note
-                traffic_all = live
+                traffic_all = {k: v for k, v in live.items() if not k.startswith("_")}
+                rocprof_us, rocprof_calls = live.get("_avg_us_in_graph", {}), live.get("_calls_in_graph", {})
             else:
                 traffic_all = None
                 traffic_source = (traffic_source or "") + " [live rocprofv3 passes unavailable: %s]" % note
@@ -996,6 +1013,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": (traffic / (ab[dom] * nb)) if traffic else None, "traffic_all_kernels": traffic_all,
+                         # the same kernel's average duration by rocprofv3 --kernel-trace --stats of a child run that replays the K steps as one
+                         # graph (the timed region's launch mode; `launch_ms` above is from HIP events around eager launches), and the fraction it gives
+                         "launch_ms_rocprof_in_graph": (rocprof_us[dom] * 1e-3) if dom in rocprof_us else None,
+                         "frac_rocprof_in_graph": (ab[dom] * nb / (rocprof_us[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS) if dom in rocprof_us else None,
+                         "rocprof_in_graph_us": rocprof_us or None, "rocprof_in_graph_calls": rocprof_calls or None,
                          "launch_ms": dom_ms, "bytes_per_launch": ab[dom] * nb,
                          "mfma_util": mfma_util, "mfma_util_source": mfma_source,
                          "all_kernels_ms": kinds,
